@@ -1,0 +1,228 @@
+// fp256.cuh -- arithmetic in Z/p, p = 2^256 - 351*2^32 + 1 (the "MiMC prime" of the reference,
+// starks/utils.py:22, starks/modp.py:25-106), written for gfx950 integer VALUs.
+//
+// Representation: 8 x u32 little-endian limbs ("limb form").  Values are kept LAZILY reduced in
+// [0, 2^256); because 2^256 == c (mod p) with c = 2^256 - p = 351*2^32 - 1 (41 bits), a carry out of
+// limb 7 is folded back by adding c, and a 512-bit product hi*2^256 + lo folds to lo + hi*c.
+// `fp_canon` maps to the unique residue in [0, p) -- done once where a value leaves the device, which
+// makes results bit-identical to the reference's `int(n) % p` after every op (modp.py:36).
+//
+// Every function is total on [0, 2^256) inputs (double folds are handled), so unreduced inputs such as
+// field(b'\xff'*32) (modp.py:33-34) are safe.
+//
+// All functions are __host__ __device__: the same code builds the twiddle tables on the host and is
+// unit-tested on the CPU (tests/test_fp256_host.py) against the oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FP_HD __host__ __device__ __forceinline__
+
+struct fp {
+  uint32_t v[8];
+};
+
+#define FP_P0 0x00000001u
+#define FP_P1 0xfffffea1u
+#define FP_PX 0xffffffffu /* limbs 2..7 of p */
+#define FP_C0 0xffffffffu /* c = 2^256 - p, limb 0 */
+#define FP_C1 0x0000015eu /* limb 1 (350) */
+
+FP_HD uint32_t fp_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) {
+  return __builtin_addc(a, b, cin, cout);
+}
+FP_HD uint32_t fp_subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t* bout) {
+  return __builtin_subc(a, b, bin, bout);
+}
+
+FP_HD fp fp_zero() {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = 0;
+  return r;
+}
+FP_HD fp fp_one() {
+  fp r = fp_zero();
+  r.v[0] = 1;
+  return r;
+}
+FP_HD fp fp_from_u32(uint32_t x) {
+  fp r = fp_zero();
+  r.v[0] = x;
+  return r;
+}
+
+// r = a + (m ? c : 0) on all 8 limbs, returns carry out.  m is 0 or 1.
+FP_HD uint32_t fp_add_c_masked(fp& a, uint32_t m) {
+  uint32_t mask = 0u - m, cy;
+  a.v[0] = fp_addc(a.v[0], FP_C0 & mask, 0, &cy);
+  a.v[1] = fp_addc(a.v[1], FP_C1 & mask, cy, &cy);
+#pragma unroll
+  for (int i = 2; i < 8; ++i) a.v[i] = fp_addc(a.v[i], 0, cy, &cy);
+  return cy;
+}
+// a += (m ? c : 0) when a is known to be < 2^96 - 2^42 (after a second wrap): 3 limbs suffice.
+FP_HD void fp_add_c_masked_low(fp& a, uint32_t m) {
+  uint32_t mask = 0u - m, cy;
+  a.v[0] = fp_addc(a.v[0], FP_C0 & mask, 0, &cy);
+  a.v[1] = fp_addc(a.v[1], FP_C1 & mask, cy, &cy);
+  a.v[2] = fp_addc(a.v[2], 0, cy, &cy);
+}
+FP_HD uint32_t fp_sub_c_masked(fp& a, uint32_t m) {
+  uint32_t mask = 0u - m, bw;
+  a.v[0] = fp_subb(a.v[0], FP_C0 & mask, 0, &bw);
+  a.v[1] = fp_subb(a.v[1], FP_C1 & mask, bw, &bw);
+#pragma unroll
+  for (int i = 2; i < 8; ++i) a.v[i] = fp_subb(a.v[i], 0, bw, &bw);
+  return bw;
+}
+
+// (a + b) mod p, lazily reduced.  modp.py:43-45.
+FP_HD fp fp_add(const fp& a, const fp& b) {
+  fp r;
+  uint32_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = fp_addc(a.v[i], b.v[i], cy, &cy);
+  uint32_t cy2 = fp_add_c_masked(r, cy);  // 2^256 == c
+  fp_add_c_masked_low(r, cy2);            // second wrap leaves r < 2^42, cannot wrap again
+  return r;
+}
+
+// (a - b) mod p, lazily reduced.  modp.py:47-49.
+FP_HD fp fp_sub(const fp& a, const fp& b) {
+  fp r;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = fp_subb(a.v[i], b.v[i], bw, &bw);
+  uint32_t bw2 = fp_sub_c_masked(r, bw);  // -2^256 == -c
+  // second borrow: r = 2^256 - d with d < 2^41 (limbs 2..7 all ones); subtracting c again only
+  // touches limbs 0..1 and cannot borrow out of them
+  uint32_t mask = 0u - bw2, b3;
+  r.v[0] = fp_subb(r.v[0], FP_C0 & mask, 0, &b3);
+  r.v[1] = fp_subb(r.v[1], FP_C1 & mask, b3, &b3);
+  return r;
+}
+
+// unique residue in [0, p): subtract p once if a >= p (a < 2^256 < 2p).
+FP_HD fp fp_canon(const fp& a) {
+  fp t;
+  uint32_t bw;
+  t.v[0] = fp_subb(a.v[0], FP_P0, 0, &bw);
+  t.v[1] = fp_subb(a.v[1], FP_P1, bw, &bw);
+#pragma unroll
+  for (int i = 2; i < 8; ++i) t.v[i] = fp_subb(a.v[i], FP_PX, bw, &bw);
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = bw ? a.v[i] : t.v[i];
+  return r;
+}
+
+FP_HD fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a); }
+
+FP_HD bool fp_eq_canon(const fp& a, const fp& b) {
+  uint32_t d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];
+  return d == 0;
+}
+
+// 256x256 -> 512 bit schoolbook product, column (product-scanning) order: one 32x32+64 multiply-add
+// (v_mad_u64_u32) plus one carry add per partial product, 96-bit running column accumulator.
+FP_HD void fp_mul_wide(const uint32_t a[8], const uint32_t b[8], uint32_t t[16]) {
+  uint64_t acc = 0;
+  uint32_t top = 0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) {
+    const int lo = k < 8 ? 0 : k - 7;
+    const int hi = k < 8 ? k : 7;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) {
+      uint64_t pr = (uint64_t)a[i] * b[k - i];
+      acc += pr;
+      top += (acc < pr) ? 1u : 0u;
+    }
+    t[k] = (uint32_t)acc;
+    acc = (acc >> 32) | ((uint64_t)top << 32);
+    top = 0;
+  }
+  t[15] = (uint32_t)acc;
+}
+
+// fold a 512-bit value t = hi*2^256 + lo into [0, 2^256):  t == lo + hi*c,  hi*c = (hi*351 << 32) - hi.
+FP_HD fp fp_reduce_wide(const uint32_t t[16]) {
+  // A = hi * 351  (9 limbs)
+  uint32_t A[9];
+  uint64_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t m = (uint64_t)t[8 + i] * 351u + cy;
+    A[i] = (uint32_t)m;
+    cy = m >> 32;
+  }
+  A[8] = (uint32_t)cy;
+  // R = lo + (A << 32) - hi        (10 limbs, non-negative because A<<32 >= hi)
+  uint32_t R[10];
+  uint32_t c1 = 0, b1 = 0;
+  // limb 0: lo[0] + 0 - hi[0]
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint32_t lo = i < 8 ? t[i] : 0u;
+    uint32_t as = (i >= 1 && i <= 9) ? A[i - 1] : 0u;
+    uint32_t hi = i < 8 ? t[8 + i] : 0u;
+    uint32_t s = fp_addc(lo, as, c1, &c1);
+    R[i] = fp_subb(s, hi, b1, &b1);
+  }
+  // (c1 and b1 cancel at the top: R < 2^298 fits in 10 limbs, so final c1 == b1.)
+  // second fold: h2 = R[8] + R[9]*2^32 (< 2^42);  r = R[0..7] + (h2*351 << 32) - h2
+  uint64_t h2 = (uint64_t)R[8] | ((uint64_t)R[9] << 32);
+  uint64_t B = h2 * 351u;  // < 2^51
+  fp r;
+  uint32_t c2 = 0, b2 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t as = i == 1 ? (uint32_t)B : (i == 2 ? (uint32_t)(B >> 32) : 0u);
+    uint32_t hs = i == 0 ? R[8] : (i == 1 ? R[9] : 0u);
+    uint32_t s = fp_addc(R[i], as, c2, &c2);
+    r.v[i] = fp_subb(s, hs, b2, &b2);
+  }
+  // net carry out of limb 7 is c2 - b2 in {0, 1} (the value is non-negative)
+  uint32_t over = c2 - b2;
+  fp_add_c_masked_low(r, over);  // after a wrap r < 2^84: three limbs suffice
+  return r;
+}
+
+// (a * b) mod p, lazily reduced.  modp.py:51-53.
+FP_HD fp fp_mul(const fp& a, const fp& b) {
+  uint32_t t[16];
+  fp_mul_wide(a.v, b.v, t);
+  return fp_reduce_wide(t);
+}
+
+FP_HD fp fp_sqr(const fp& a) { return fp_mul(a, a); }
+
+// a^e for a 64-bit exponent (square-and-multiply, numbertype.py:68-84 computes the same value).
+FP_HD fp fp_pow_u64(fp a, uint64_t e) {
+  fp r = fp_one();
+  while (e) {
+    if (e & 1) r = fp_mul(r, a);
+    a = fp_sqr(a);
+    e >>= 1;
+  }
+  return r;
+}
+
+// ---- wire form <-> limb form ------------------------------------------------------------------
+// Wire form = 32 bytes big-endian (modp.py:94-95).  Word k of the wire form read as a little-endian
+// u32 is bswap(limb[7-k]).
+FP_HD uint32_t fp_bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+FP_HD fp fp_from_wire_words(const uint32_t w[8]) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = fp_bswap32(w[7 - i]);
+  return r;
+}
+FP_HD void fp_to_wire_words(const fp& a, uint32_t w[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = fp_bswap32(a.v[7 - i]);
+}

@@ -1,0 +1,419 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: imports the LIVE reference (read-only, /root/reference) and
+writes input/output fixtures for the STARK hot path into tests/golden/*.json.
+
+Run (in the build container only -- the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/generate.py [--big]
+
+What is called from the reference (all live, importable code):
+    starks.modp.IntegersModP              (starks/modp.py:25-106)
+    starks.fft.NonBinaryFFT / fft_1d / mul_polys   (starks/fft.py:256-345)
+    starks.merkle_tree.merkelize / mk_branch / verify_branch / permute4 (merkle_tree.py:11-86)
+    starks.utils.get_power_cycle / get_pseudorandom_indices (utils.py:30-38, 60-90)
+    starks.poly_utils.multi_interp_4 / multi_inv / lagrange_interp (poly_utils.py)
+    starks.compression.compress_fri / bin_length (compression.py)
+    starks.polynomial.polynomials_over     (polynomial.py)
+
+The FRI driver itself (SmoothSubgroupFRI) is a comment block in the reference
+(starks/fri.py:176-366), so it cannot be imported.  `ref_prove` / `ref_verify` below
+drive the reference's live primitives in the order that comment block prescribes
+(fri.py:189-266 prover, fri.py:268-366 verifier); every arithmetic step is executed
+by reference code, only the sequencing is written here.
+
+Fixtures hold data only (inputs, outputs, digests) -- no reference source text.
+"""
+import argparse
+import hashlib
+import json
+import os
+import struct
+import sys
+import time
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.setrecursionlimit(10000)
+
+from starks.modp import IntegersModP  # noqa: E402
+from starks.polynomial import polynomials_over  # noqa: E402
+from starks.fft import NonBinaryFFT, fft_1d, mul_polys  # noqa: E402
+from starks.merkle_tree import merkelize, mk_branch, verify_branch, permute4, get_index_in_permuted  # noqa: E402
+from starks.utils import get_power_cycle, get_pseudorandom_indices  # noqa: E402
+from starks.poly_utils import multi_interp_4, multi_inv, lagrange_interp  # noqa: E402
+from starks.compression import compress_fri, decompress_fri, compress_branches, bin_length  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = 2**256 - 2**32 * 351 + 1
+F = IntegersModP(P)
+polysOver = polynomials_over(F).factory
+
+
+def hx(v):
+    """field element / int / bytes -> hex string (ints as 64 hex digits, big-endian)."""
+    if isinstance(v, bytes):
+        return v.hex()
+    return int(v).to_bytes(32, "big").hex()
+
+
+def sha(bs):
+    return hashlib.sha256(bs).hexdigest()
+
+
+def seeded(seed, i):
+    """x_i = BLAKE2s(seed_le64 || i_le64) mod p  (SURVEY 8(d) synthetic input)."""
+    d = hashlib.blake2s(struct.pack("<QQ", seed, i)).digest()
+    return int.from_bytes(d, "big") % P
+
+
+def root_of_order(n):
+    return F(7) ** ((P - 1) // n)
+
+
+def mimc_trace(t0, steps):
+    """MiMC trace t_{i+1} = t_i^3 + k_{i mod 64}, k_i = (i^7) xor 42  (utils.py:24-25, test_fri.py:112)."""
+    ks = [(i**7) ^ 42 for i in range(64)]
+    out = [t0 % P]
+    for i in range(steps - 1):
+        out.append((out[-1] ** 3 + ks[i % 64]) % P)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# FRI sequencing over the reference's live primitives (order of calls: fri.py:189-266 / 268-366)
+# ----------------------------------------------------------------------------------------------
+def ref_prove(f, root_of_unity, maxdeg_plus_1, exclude_multiples_of=0, samples=40, trace=None):
+    values = NonBinaryFFT(F, root_of_unity).fft(f)
+    if maxdeg_plus_1 <= 16:
+        return [[x.to_bytes() for x in values]]
+    xs = get_power_cycle(root_of_unity, F)
+    assert len(values) == len(xs)
+    m = merkelize(values)
+    special_x = F(m[1])
+    q = len(xs) // 4
+    x_polys = multi_interp_4(
+        F,
+        [[xs[i + q * j] for j in range(4)] for i in range(q)],
+        [[values[i + q * j] for j in range(4)] for i in range(q)])
+    column = [p(special_x) for p in x_polys]
+    m2 = merkelize(column)
+    ys = get_pseudorandom_indices(m2[1], len(column), samples, exclude_multiples_of=exclude_multiples_of)
+    branches = []
+    for y in ys:
+        branches.append([mk_branch(m2, y)] + [mk_branch(m, y + q * j) for j in range(4)])
+    if trace is not None:
+        trace.append({"n": len(xs), "root_m": m[1].hex(), "root_m2": m2[1].hex(), "ys": ys})
+    o = [m2[1], branches]
+    column_poly = NonBinaryFFT(F, root_of_unity ** 4).inv_fft(column)
+    # NB the recursion does not forward `samples`: later rounds use the default 40 (fri.py:262-266)
+    return [o] + ref_prove(column_poly, root_of_unity ** 4, maxdeg_plus_1 // 4,
+                           exclude_multiples_of=exclude_multiples_of, trace=trace)
+
+
+def ref_verify(proof, merkle_root, root_of_unity, maxdeg_plus_1, exclude_multiples_of=0, samples=40):
+    testval = root_of_unity
+    roudeg = 1
+    while testval != 1:
+        roudeg *= 2
+        testval = testval * testval
+    quartic = [1, root_of_unity ** (roudeg // 4), root_of_unity ** (roudeg // 2), root_of_unity ** (roudeg * 3 // 4)]
+    for prf in proof[:-1]:
+        root2, branches = prf
+        special_x = F(merkle_root)
+        ys = get_pseudorandom_indices(root2, roudeg // 4, samples, exclude_multiples_of=exclude_multiples_of)
+        xcoords, rows, columnvals = [], [], []
+        for i, y in enumerate(ys):
+            x1 = root_of_unity ** y
+            xcoords.append([(quartic[j] * x1) for j in range(4)])
+            rows.append([verify_branch(merkle_root, y + (roudeg // 4) * j, b, output_as_int=True)
+                         for j, b in zip(range(4), branches[i][1:])])
+            columnvals.append(verify_branch(root2, y, branches[i][0], output_as_int=True))
+        polys = multi_interp_4(F, xcoords, rows)
+        for p, c in zip(polys, columnvals):
+            assert p(special_x) == c
+        merkle_root = root2
+        root_of_unity = root_of_unity ** 4
+        maxdeg_plus_1 //= 4
+        roudeg //= 4
+    data = [int.from_bytes(x, "big") for x in proof[-1]]
+    assert maxdeg_plus_1 <= 16
+    mtree = merkelize(data)
+    assert mtree[1] == merkle_root
+    powers = get_power_cycle(root_of_unity, F)
+    pts = [x for x in range(len(data)) if x % exclude_multiples_of] if exclude_multiples_of else list(range(len(data)))
+    poly = lagrange_interp(F, [powers[x] for x in pts[:maxdeg_plus_1]], [data[x] for x in pts[:maxdeg_plus_1]])
+    for x in pts[maxdeg_plus_1:]:
+        assert poly(powers[x]) == data[x]
+    return True
+
+
+def proof_bytes(proof):
+    """'Proof bytes' = bin_length-style join of compress_fri(proof) (compression.py:1-32,104-105)."""
+    return b"".join((b"\xff" if len(x) == 32 else b"") + x for x in compress_fri(proof))
+
+
+def proof_flat(proof):
+    """Uncompressed canonical flattening: root || branches (all 32-B nodes in order) per round, then final values."""
+    out = []
+    for root, branches in proof[:-1]:
+        out.append(root)
+        for bset in branches:
+            for b in bset:
+                out.extend(b)
+    out.extend(proof[-1])
+    return b"".join(out)
+
+
+def dump(name, obj):
+    path = os.path.join(HERE, name)
+    with open(path, "w") as fh:
+        json.dump(obj, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+    print("wrote %s (%d bytes)" % (name, os.path.getsize(path)))
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_field():
+    a = seeded(1, 0)
+    b = seeded(1, 1)
+    cases = []
+    specials = [0, 1, 2, P - 1, P - 2, 2**255, 2**128, 2**32 * 351 - 1, (P - 1) // 2, a, b,
+                seeded(1, 2), seeded(1, 3), 0xffffffff, 0xffffffffffffffff, 2**224 - 1]
+    for x in specials:
+        for y in specials:
+            fx, fy = F(x), F(y)
+            cases.append({"a": hx(x), "b": hx(y), "add": hx(fx + fy), "sub": hx(fx - fy), "mul": hx(fx * fy)})
+    inv = [{"a": hx(x), "inv": hx(F(x).inverse())} for x in specials if x % P]
+    pows = [{"base": hx(7), "e": str(e), "pow": hx(F(7) ** e)} for e in
+            [0, 1, 2, 3, 65537, (P - 1) // 2, (P - 1) // 512, (P - 1) // 2**32, P - 2]]
+    unreduced = F(b"\xff" * 32)
+    dump("field.json", {
+        "p": hex(P), "two_adicity": 32, "cases": cases, "inverse": inv, "pow": pows,
+        "kat_2_256": hx(F(2**256)),                 # test_modpy.py:35
+        "bytes_ctor_unreduced_n": hex(unreduced.n),  # modp.py:33-34
+        "bytes_ctor_times_one": hx(unreduced * 1),
+        "roots": {str(k): hx(root_of_order(2**k)) for k in range(0, 33)},
+    })
+
+
+def gen_ntt(big):
+    out = {"seed": 0x5eed, "cases": []}
+    # MiMC prime, power-of-two sizes, full vectors
+    for n, n_in in [(4, 4), (8, 4), (8, 8), (16, 16), (32, 7), (64, 64), (256, 256), (512, 100), (1024, 1024)]:
+        w = root_of_order(n)
+        xs = [seeded(0x5eed, i) for i in range(n_in)]
+        fwd = fft_1d(F, [F(x) for x in xs], P, w, inv=False)
+        inv = fft_1d(F, [F(x) for x in xs], P, w, inv=True)
+        rt = fft_1d(F, fwd, P, w, inv=True)
+        assert [int(v) for v in rt] == xs + [0] * (n - n_in)
+        case = {"n": n, "n_in": n_in, "w": hx(w), "sha_fwd": sha(b"".join(int(v).to_bytes(32, "big") for v in fwd)),
+                "sha_inv": sha(b"".join(int(v).to_bytes(32, "big") for v in inv))}
+        if n <= 64:
+            case["in"] = [hx(x) for x in xs]
+            case["fwd"] = [hx(v) for v in fwd]
+            case["inv"] = [hx(v) for v in inv]
+        out["cases"].append(case)
+    # reference test vectors: test_fft.py:98-130 and Appendix A
+    f31 = IntegersModP(31)
+    w6 = f31(3) ** 5
+    ev = NonBinaryFFT(f31, w6).fft(polynomials_over(f31).factory([0, 1, 2, 3]))
+    back = NonBinaryFFT(f31, w6).inv_fft(ev)
+    out["mod31_n6"] = {"w": int(w6), "coeffs": [0, 1, 2, 3], "fwd": [int(v) for v in ev],
+                       "inv_roundtrip": [int(v) for v in back.coefficients]}
+    w8 = root_of_order(8)
+    ev8 = NonBinaryFFT(F, w8).fft(polysOver([0, 1, 2, 3]))
+    out["mimc_n8_0123"] = {"w": hx(w8), "fwd": [hx(v) for v in ev8]}
+    # inv_fft strips trailing zeros (polynomial.py:58)
+    vals = fft_1d(F, [F(5), F(6), F(7)], P, root_of_order(16), inv=False)
+    poly = NonBinaryFFT(F, root_of_order(16)).inv_fft(vals)
+    out["inv_fft_strip"] = {"n": 16, "values": [hx(v) for v in vals], "coeffs": [hx(c) for c in poly.coefficients]}
+    # mul_polys: unscaled product (fft.py:334-345)
+    w512 = root_of_order(512)
+    prod = mul_polys([F(v) for v in range(4)], [F(v) for v in range(4)], w512)
+    out["mul_polys_0123"] = {"n": 512, "first16": [int(v) for v in prod[:16]],
+                             "sha": sha(b"".join(int(v).to_bytes(32, "big") for v in prod))}
+    # bigger: digests only
+    sizes = [2**12, 2**14, 2**16]
+    if big:
+        sizes += [2**18, 2**20]
+    for n in sizes:
+        t0 = time.time()
+        w = root_of_order(n)
+        xs = [F(seeded(0x5eed, i)) for i in range(n)]
+        fwd = fft_1d(F, xs, P, w, inv=False)
+        inv = fft_1d(F, xs, P, w, inv=True)
+        out["cases"].append({"n": n, "n_in": n, "w": hx(w),
+                             "sha_fwd": sha(b"".join(int(v).to_bytes(32, "big") for v in fwd)),
+                             "sha_inv": sha(b"".join(int(v).to_bytes(32, "big") for v in inv)),
+                             "first": hx(fwd[0]), "last": hx(fwd[-1]), "mid": hx(fwd[n // 2 + 1]),
+                             "ref_seconds_fwd_plus_inv": round(time.time() - t0, 2)})
+        print("ntt n=%d done in %.1fs" % (n, time.time() - t0), flush=True)
+    dump("ntt.json", out)
+
+
+def gen_merkle():
+    out = {}
+    t = merkelize([x.to_bytes(32, "big") for x in range(128)])
+    out["range128"] = {"root": t[1].hex(), "branch59": [b.hex() for b in mk_branch(t, 59)],
+                       "tree_sha": sha(b"".join(t)), "len": len(t)}
+    assert verify_branch(t[1], 59, mk_branch(t, 59), output_as_int=True) == 59
+    t = merkelize([x.to_bytes(32, "big") for x in range(256)])
+    out["range256"] = {"root": t[1].hex(), "branch59_len": len(mk_branch(t, 59)), "tree_sha": sha(b"".join(t))}
+    t = merkelize([F(1), F(2), F(3), F(4)])
+    out["f1234"] = {"root": t[1].hex(), "tree": [b.hex() for b in t]}
+    out["permute4_8"] = permute4(list(range(8)))
+    out["index_in_permuted"] = [[x, L, get_index_in_permuted(x, L)] for L in (4, 8, 64, 1024) for x in (0, 1, 2, 3, L // 4, L // 2 + 1, L - 1)]
+    trees = []
+    for n in (4, 8, 16, 64, 512, 4096):
+        vals = [seeded(7, i) for i in range(n)]
+        t = merkelize([F(v) for v in vals])
+        idx = sorted({0, 1, n // 4, n // 2 + 1, n - 1, (5 * n) // 7})
+        trees.append({"n": n, "seed": 7, "root": t[1].hex(), "tree_sha": sha(b"".join(t)),
+                      "branches": {str(i): [b.hex() for b in mk_branch(t, i)] for i in idx}})
+    out["seeded"] = trees
+    # ints, bytes and elements give the same tree (merkle_tree.py:47-53)
+    ti = merkelize([5, 6, 7, 8])
+    tb = merkelize([(5).to_bytes(32, "big"), (6).to_bytes(32, "big"), (7).to_bytes(32, "big"), (8).to_bytes(32, "big")])
+    te = merkelize([F(5), F(6), F(7), F(8)])
+    assert ti == tb == te
+    out["mixed5678_root"] = ti[1].hex()
+    # blake2s KATs straight from hashlib (RFC 7693 BLAKE2s-256, unkeyed)
+    out["blake2s"] = [{"msg": m.hex(), "digest": hashlib.blake2s(m).digest().hex()} for m in
+                      [b"", b"abc", bytes(range(64)), bytes(range(32)), b"\x00" * 64, bytes(range(65)), bytes(range(200))]]
+    dump("merkle.json", out)
+
+
+def gen_utils():
+    out = {}
+    f31 = IntegersModP(31)
+    out["power_cycle_mod31"] = [int(v) for v in get_power_cycle(f31(3) ** 5, f31)]  # test_utils.py:30
+    out["power_cycle_w64_sha"] = sha(b"".join(v.to_bytes() for v in get_power_cycle(root_of_order(64), F)))
+    out["power_cycle_w8"] = [hx(v) for v in get_power_cycle(root_of_order(8), F)]
+    root128 = merkelize([x.to_bytes(32, "big") for x in range(128)])[1]
+    cases = []
+    for entropy in (root128, hashlib.blake2s(b"entropy").digest(), b"\x00" * 32, b"\xff" * 32):
+        for modulus, count, excl in [(1024, 6, 8), (1024, 6, 0), (32768, 40, 8), (32768, 40, 0), (128, 40, 0),
+                                     (2**21, 40, 8), (512, 80, 8), (8, 40, 4), (2**24 - 1, 12, 0), (64, 9, 2), (96, 17, 3)]:
+            cases.append({"entropy": entropy.hex(), "modulus": modulus, "count": count, "exclude": excl,
+                          "out": get_pseudorandom_indices(entropy, modulus, count, exclude_multiples_of=excl)})
+    out["pseudorandom_indices"] = cases
+    # multi_inv incl. zeros (test_poly_utils.py:74-105)
+    vals = [F(0), F(1), F(seeded(3, 0)), F(0), F(P - 1), F(seeded(3, 1))]
+    out["multi_inv"] = {"in": [hx(v) for v in vals], "out": [hx(v) for v in multi_inv(F, vals)]}
+    dump("utils.json", out)
+
+
+def gen_fold():
+    """One FRI fold (fri.py:236-242) on seeded values with a given unreduced challenge."""
+    out = []
+    for n, sx_bytes in [(16, b"\x00" * 31 + b"\x05"), (64, hashlib.blake2s(b"sx").digest()), (256, b"\xff" * 32),
+                        (1024, hashlib.blake2s(b"sx2").digest())]:
+        w = root_of_order(n)
+        xs = get_power_cycle(w, F)
+        values = [F(seeded(11, i)) for i in range(n)]
+        q = n // 4
+        polys = multi_interp_4(F, [[xs[i + q * j] for j in range(4)] for i in range(q)],
+                               [[values[i + q * j] for j in range(4)] for i in range(q)])
+        sx = F(sx_bytes)
+        col = [p(sx) for p in polys]
+        out.append({"n": n, "seed": 11, "w": hx(w), "special_x_bytes": sx_bytes.hex(),
+                    "column": [hx(c) for c in col] if n <= 64 else None,
+                    "column_sha": sha(b"".join(c.to_bytes() for c in col))})
+    dump("fold.json", out)
+
+
+def fri_record(name, coeffs, w, maxdeg, excl, samples=40, keep_proof=False, coeff_desc=None):
+    t0 = time.time()
+    trace = []
+    poly = polysOver(coeffs)
+    proof = ref_prove(poly, w, maxdeg, exclude_multiples_of=excl, samples=samples, trace=trace)
+    secs = time.time() - t0
+    evals = NonBinaryFFT(F, w).fft(poly)
+    mroot = merkelize(evals)[1]
+    ok = ref_verify(proof, mroot, w, maxdeg, exclude_multiples_of=excl, samples=samples) if samples == 40 else None
+    pb = proof_bytes(proof)
+    flat = proof_flat(proof)
+    rec = {"name": name, "coeffs": coeff_desc, "n_coeffs": len(coeffs), "w": hx(w), "maxdeg_plus_1": maxdeg,
+           "exclude_multiples_of": excl, "samples": samples, "rounds": trace, "len_proof": len(proof),
+           "branch_lens": [[len(b) for b in proof[r][1][0]] for r in range(len(proof) - 1)],
+           "final_values": [x.hex() for x in proof[-1]], "eval_root": mroot.hex(),
+           "proof_bytes_len": len(pb), "proof_bytes_sha": sha(pb), "flat_len": len(flat), "flat_sha": sha(flat),
+           "ref_verified": ok, "ref_seconds": round(secs, 2)}
+    if keep_proof:
+        with open(os.path.join(HERE, name + ".proof.bin"), "wb") as fh:
+            fh.write(pb)
+        with open(os.path.join(HERE, name + ".flat.bin"), "wb") as fh:
+            fh.write(flat)
+    print("fri %s: %d rounds, %.1fs, verified=%s" % (name, len(proof), secs, ok), flush=True)
+    return rec
+
+
+def gen_fri(big):
+    recs = []
+    # the reference's own (commented) test input: test_fri.py:105-134
+    coeffs = [(i**7) ^ 42 for i in range(512)]
+    recs.append(fri_record("fri_deg512", coeffs, root_of_order(512), 512, 0, keep_proof=True, coeff_desc="(i**7)^42, i<512"))
+    # test_fri.py:159-182: poly = range(256), domain 1024
+    recs.append(fri_record("fri_range256_dom1024", list(range(256)), root_of_order(1024), 256, 0, coeff_desc="i, i<256"))
+    # base case only (maxdeg <= 16): proof = [values]
+    recs.append(fri_record("fri_base16", list(range(1, 17)), root_of_order(64), 16, 0, coeff_desc="i+1, i<16"))
+    # exclusion + extension 8, MiMC trace, steps 2^7 / 2^9
+    for k in (7, 9, 11):
+        steps = 2**k
+        g2 = root_of_order(8 * steps)
+        g1 = g2 ** 8
+        tr = mimc_trace(3, steps)
+        pcoef = NonBinaryFFT(F, g1).inv_fft([F(v) for v in tr]).coefficients
+        recs.append(fri_record("fri_mimc_2_%d" % k, [int(c) for c in pcoef], g2, steps, 8,
+                               keep_proof=(k == 7), coeff_desc="iNTT_G1(mimc_trace(3, 2^%d))" % k))
+    # non-default sample count: only round 0 uses it (fri.py:262-266 recursion drops the argument)
+    recs.append(fri_record("fri_samples12", coeffs, root_of_order(2048), 512, 0, samples=12, coeff_desc="(i**7)^42, i<512"))
+    if big:
+        steps = 2**14
+        g2 = root_of_order(8 * steps)
+        g1 = g2 ** 8
+        tr = mimc_trace(3, steps)
+        pcoef = NonBinaryFFT(F, g1).inv_fft([F(v) for v in tr]).coefficients
+        recs.append(fri_record("fri_mimc_2_14", [int(c) for c in pcoef], g2, steps, 8,
+                               coeff_desc="iNTT_G1(mimc_trace(3, 2^14))"))
+    dump("fri.json", recs)
+
+
+def gen_lde():
+    out = []
+    for k in (4, 8, 10):
+        steps = 2**k
+        g2 = root_of_order(8 * steps)
+        g1 = g2 ** 8
+        tr = mimc_trace(3, steps)
+        pc = NonBinaryFFT(F, g1).inv_fft([F(v) for v in tr])
+        ext = NonBinaryFFT(F, g2).fft(pc)
+        assert [int(v) for v in ext[::8]] == tr
+        out.append({"steps": steps, "ext": 8, "g2": hx(g2), "trace_t0": 3,
+                    "trace_sha": sha(b"".join(v.to_bytes(32, "big") for v in tr)),
+                    "coeff_sha": sha(b"".join(int(c).to_bytes(32, "big") for c in pc.coefficients + [0] * (steps - len(pc.coefficients)))),
+                    "lde_sha": sha(b"".join(v.to_bytes() for v in ext)),
+                    "lde": [hx(v) for v in ext] if k == 4 else None,
+                    "trace_last": hx(tr[-1])})
+    dump("lde.json", out)
+
+
+def gen_compression():
+    br = [[b"a" * 32, b"b" * 32, b"a" * 32], [b"b" * 32, b"c" * 32]]
+    c = compress_branches(br)
+    dump("compression.json", {"branches": [[x.hex() for x in b] for b in br], "compressed": [x.hex() for x in c],
+                              "bin_length": bin_length(c)})
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="also the slow cases (2^18/2^20 NTT, 2^14-step FRI)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    todo = a.only.split(",") if a.only else ["field", "merkle", "utils", "fold", "lde", "compression", "fri", "ntt"]
+    for name in todo:
+        fn = globals()["gen_" + name]
+        if name in ("ntt", "fri"):
+            fn(a.big)
+        else:
+            fn()
