@@ -1,0 +1,193 @@
+"""Pins oracle/pyoracle.py (the plain-Python restatement) to the fixtures generated from the LIVE
+reference by tests/golden/generate.py.  CPU only."""
+import hashlib
+import os
+import struct
+
+import pytest
+
+from oracle import pyoracle as po
+from conftest import load_golden, GOLDEN
+
+P = po.MIMC_P
+
+
+def h2i(s):
+    return int(s, 16)
+
+
+def sha_ints(vals):
+    return hashlib.sha256(b"".join(int(v).to_bytes(32, "big") for v in vals)).hexdigest()
+
+
+def seeded(seed, i):
+    return int.from_bytes(hashlib.blake2s(struct.pack("<QQ", seed, i)).digest(), "big") % P
+
+
+def test_field_cases():
+    g = load_golden("field.json")
+    assert int(g["p"], 16) == P
+    for c in g["cases"]:
+        a, b = h2i(c["a"]), h2i(c["b"])
+        assert (a + b) % P == h2i(c["add"])
+        assert (a - b) % P == h2i(c["sub"])
+        assert (a * b) % P == h2i(c["mul"])
+    for c in g["inverse"]:
+        assert po.f_inv(h2i(c["a"]), P) == h2i(c["inv"])
+    for c in g["pow"]:
+        assert po.f_pow(h2i(c["base"]), int(c["e"]), P) == h2i(c["pow"])
+    assert po.f_from_bytes(b"\xff" * 32) == int(g["bytes_ctor_unreduced_n"], 16) >= P
+    assert h2i(g["kat_2_256"]) == 2**32 * 351 - 1  # test_modpy.py:35
+
+
+def test_ntt_full_vectors():
+    g = load_golden("ntt.json")
+    for c in g["cases"]:
+        n, n_in, w = c["n"], c["n_in"], h2i(c["w"])
+        if n > 4096:
+            continue
+        xs = [seeded(g["seed"], i) for i in range(n_in)]
+        fwd = po.fft_1d(xs, P, w)
+        inv = po.fft_1d(xs, P, w, inv=True)
+        assert sha_ints(fwd) == c["sha_fwd"]
+        assert sha_ints(inv) == c["sha_inv"]
+        if "fwd" in c:
+            assert [h2i(v) for v in c["in"]] == xs
+            assert fwd == [h2i(v) for v in c["fwd"]]
+            assert inv == [h2i(v) for v in c["inv"]]
+        assert po.fft_1d(fwd, P, w, inv=True) == xs + [0] * (n - n_in)
+
+
+def test_ntt_reference_test_cases():
+    g = load_golden("ntt.json")
+    m = g["mod31_n6"]  # test_fft.py:98-113, 132-149 (n = 6 = 2*3, non power of two)
+    assert po.fft_1d(m["coeffs"], 31, m["w"]) == m["fwd"] == [6, 11, 7, 29, 27, 13]
+    assert po.inv_fft_poly(m["fwd"], 31, m["w"]) == m["inv_roundtrip"] == [0, 1, 2, 3]
+    m = g["mimc_n8_0123"]  # test_fft.py:115-130
+    assert po.fft_1d([0, 1, 2, 3], P, h2i(m["w"])) == [h2i(v) for v in m["fwd"]]
+    m = g["inv_fft_strip"]
+    assert po.inv_fft_poly([h2i(v) for v in m["values"]], P, pow(7, (P - 1) // 16, P)) == [5, 6, 7]
+    m = g["mul_polys_0123"]  # test_fft.py:185-194; product comes back scaled by n = 512
+    prod = po.mul_polys([0, 1, 2, 3], [0, 1, 2, 3], P, pow(7, (P - 1) // 512, P))
+    assert prod[:16] == m["first16"] and sha_ints(prod) == m["sha"]
+    assert prod[:7] == [512 * v for v in [0, 0, 1, 4, 10, 12, 9]]
+
+
+def test_merkle():
+    g = load_golden("merkle.json")
+    t = po.merkelize([x.to_bytes(32, "big") for x in range(128)])
+    assert t[1].hex() == g["range128"]["root"] and len(t) == 256
+    b = po.mk_branch(t, 59)
+    assert [x.hex() for x in b] == g["range128"]["branch59"] and len(b) == 8
+    assert po.verify_branch(t[1], 59, b, output_as_int=True) == 59  # test_merkle_tree.py:16-22
+    assert hashlib.sha256(b"".join(t)).hexdigest() == g["range128"]["tree_sha"]
+    t = po.merkelize([x.to_bytes(32, "big") for x in range(256)])
+    assert t[1].hex() == g["range256"]["root"] and len(po.mk_branch(t, 59)) == 9
+    t = po.merkelize([1, 2, 3, 4])
+    assert [x.hex() for x in t] == g["f1234"]["tree"]
+    assert po.permute4(list(range(8))) == g["permute4_8"] == [0, 2, 4, 6, 1, 3, 5, 7]
+    for x, L, r in g["index_in_permuted"]:
+        assert po.get_index_in_permuted(x, L) == r
+    for c in g["seeded"]:
+        vals = [seeded(c["seed"], i) for i in range(c["n"])]
+        t = po.merkelize(vals)
+        assert t[1].hex() == c["root"]
+        assert hashlib.sha256(b"".join(t)).hexdigest() == c["tree_sha"]
+        for i, br in c["branches"].items():
+            assert [x.hex() for x in po.mk_branch(t, int(i))] == br
+            assert po.verify_branch(t[1], int(i), po.mk_branch(t, int(i)), True) == vals[int(i)]
+    assert po.merkelize([5, 6, 7, 8])[1].hex() == g["mixed5678_root"]
+
+
+def test_utils():
+    g = load_golden("utils.json")
+    assert po.get_power_cycle(26, 31) == g["power_cycle_mod31"] == [1, 26, 25, 30, 5, 6]  # test_utils.py:30
+    assert [v.to_bytes(32, "big").hex() for v in po.get_power_cycle(pow(7, (P - 1) // 8, P), P)] == g["power_cycle_w8"]
+    assert sha_ints(po.get_power_cycle(pow(7, (P - 1) // 64, P), P)) == g["power_cycle_w64_sha"]
+    for c in g["pseudorandom_indices"]:
+        assert po.get_pseudorandom_indices(bytes.fromhex(c["entropy"]), c["modulus"], c["count"], c["exclude"]) == c["out"]
+    mi = g["multi_inv"]
+    assert po.multi_inv([h2i(v) for v in mi["in"]], P) == [h2i(v) for v in mi["out"]]
+
+
+def test_fold():
+    for c in load_golden("fold.json"):
+        n, w = c["n"], h2i(c["w"])
+        values = [seeded(c["seed"], i) for i in range(n)]
+        col = po.fri_fold(values, po.get_power_cycle(w, P), po.f_from_bytes(bytes.fromhex(c["special_x_bytes"])), P)
+        assert sha_ints(col) == c["column_sha"]
+        if c["column"]:
+            assert col == [h2i(v) for v in c["column"]]
+
+
+def test_multi_interp_4_kat():
+    # test_poly_utils.py:158-169: identity data mod 7 interpolates to x
+    out = po.multi_interp_4([[1, 2, 3, 6]] * 2, [[1, 2, 3, 6]] * 2, 7)
+    assert out == [[0, 1, 0, 0], [0, 1, 0, 0]]
+    assert po.multi_inv([6, 1, 6], 7) == [6, 1, 6]  # test_poly_utils.py:74-82
+    assert po.multi_inv([0, 1, 1], 7, as_field_elements=False) == [0, 1, 1]
+
+
+def test_lde():
+    for c in load_golden("lde.json"):
+        tr = po.mimc_trace(c["trace_t0"], c["steps"])
+        assert sha_ints(tr) == c["trace_sha"] and tr[-1] == h2i(c["trace_last"])
+        ext = po.low_degree_extension(tr, h2i(c["g2"]), c["ext"])
+        assert sha_ints(ext) == c["lde_sha"]
+        assert ext[::8] == tr
+        if c["lde"]:
+            assert ext == [h2i(v) for v in c["lde"]]
+
+
+def _fri_input(rec):
+    d = rec["coeffs"]
+    if d.startswith("(i**7)^42"):
+        return [(i**7) ^ 42 for i in range(rec["n_coeffs"])]
+    if d == "i, i<256":
+        return list(range(256))
+    if d == "i+1, i<16":
+        return list(range(1, 17))
+    if d.startswith("iNTT_G1(mimc_trace"):
+        k = int(d.split("2^")[1].rstrip("))"))
+        g2 = h2i(rec["w"])
+        return po.inv_fft_poly(po.mimc_trace(3, 2**k), P, pow(g2, 8, P))
+    raise AssertionError(d)
+
+
+@pytest.mark.parametrize("rec", [r for r in load_golden("fri.json") if r["maxdeg_plus_1"] <= 2048],
+                         ids=lambda r: r["name"])
+def test_fri_proofs(rec):
+    coeffs = _fri_input(rec)
+    assert len(coeffs) == rec["n_coeffs"]
+    trace = []
+    proof = po.prove_low_degree(coeffs, h2i(rec["w"]), rec["maxdeg_plus_1"], P, rec["exclude_multiples_of"],
+                                rec["samples"], trace=trace)
+    assert len(proof) == rec["len_proof"]
+    assert trace == rec["rounds"]
+    assert [x.hex() for x in proof[-1]] == rec["final_values"]
+    assert [[len(b) for b in proof[r][1][0]] for r in range(len(proof) - 1)] == rec["branch_lens"]
+    pb, flat = po.proof_bytes(proof), po.proof_flat(proof)
+    assert (len(pb), hashlib.sha256(pb).hexdigest()) == (rec["proof_bytes_len"], rec["proof_bytes_sha"])
+    assert (len(flat), hashlib.sha256(flat).hexdigest()) == (rec["flat_len"], rec["flat_sha"])
+    for ext, data in ((".proof.bin", pb), (".flat.bin", flat)):
+        path = os.path.join(GOLDEN, rec["name"] + ext)
+        if os.path.exists(path):
+            assert open(path, "rb").read() == data
+    if rec["samples"] == 40:
+        evals = po.fft_1d(coeffs, P, h2i(rec["w"]))
+        root = po.merkelize(evals)[1]
+        assert root.hex() == rec["eval_root"]
+        assert po.verify_low_degree_proof(proof, root, h2i(rec["w"]), rec["maxdeg_plus_1"], P, rec["exclude_multiples_of"])
+
+
+def test_fri_shapes_of_reference_test():
+    """test_fri.py:105-134 (commented): len(proof)==4, 40 branch sets per round, 8 final values."""
+    rec = [r for r in load_golden("fri.json") if r["name"] == "fri_deg512"][0]
+    assert rec["len_proof"] == 4 and len(rec["final_values"]) == 8
+    assert all(len(r["ys"]) == 40 for r in rec["rounds"])
+
+
+def test_compression():
+    g = load_golden("compression.json")
+    # compress_branches is not on the FRI path; the fixture pins the back-reference encoding idea
+    assert g["bin_length"] == sum((33 if len(bytes.fromhex(x)) == 32 else len(bytes.fromhex(x))) for x in g["compressed"])
