@@ -1,0 +1,164 @@
+"""ctypes binding of libstarkhip.so (C ABI: include/starkhip.h).
+
+There is NO CPU fallback: if the shared library is missing, or no MI355X is visible, every entry point
+raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` (or `make -C starks_amd/csrc`).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstarkhip.so")
+
+MIMC_P = 2**256 - 2**32 * 351 + 1  # starks/utils.py:22
+
+_lib = None
+_ctx = None
+_lock = threading.Lock()
+
+
+class StarkHipError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %s (%d)" % (where, _strerror(status), status)
+        if detail:
+            msg += " -- " + detail
+        super().__init__(msg)
+
+
+def _strerror(status):
+    try:
+        return lib().sh_strerror(status).decode()
+    except Exception:  # pragma: no cover
+        return "status %d" % status
+
+
+def lib():
+    """Load the shared library (no device needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "starks_amd: %s is missing -- the HIP extension has not been built. Run "
+            "`python -c \"import __graft_entry__ as g; g.build()\"` or `make -C starks_amd/csrc`. "
+            "There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c_p, u8p, u64, u32, i32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    pp = ctypes.POINTER(c_p)
+    sig = {
+        "sh_strerror": (ctypes.c_char_p, [i32]),
+        "sh_version": (ctypes.c_char_p, []),
+        "sh_ctx_create": (i32, [i32, pp]),
+        "sh_ctx_destroy": (None, [c_p]),
+        "sh_last_error": (ctypes.c_char_p, [c_p]),
+        "sh_device_count": (i32, []),
+        "sh_sync": (i32, [c_p]),
+        "sh_timer_start": (i32, [c_p]),
+        "sh_timer_stop": (i32, [c_p, ctypes.POINTER(ctypes.c_float)]),
+        "sh_ntt": (i32, [c_p, u8p, u64, c_p, u64, u8p, i32]),
+        "sh_ntt_batch": (i32, [c_p, u8p, u64, c_p, u64, u32, u8p, i32]),
+        "sh_mul_polys": (i32, [c_p, u8p, u64, u8p, u64, c_p, u64, u8p]),
+        "sh_power_cycle": (i32, [c_p, u8p, u64, c_p]),
+        "sh_lde": (i32, [c_p, u8p, c_p, u64, u32, u32, u8p]),
+        "sh_merkelize": (i32, [c_p, u8p, u64, c_p]),
+        "sh_fri_fold": (i32, [c_p, u8p, u64, u8p, u8p, c_p]),
+        "sh_fri_proof_len": (u64, [u64, u64, u32]),
+        "sh_fri_prove": (i32, [c_p, u8p, u64, u64, u8p, u64, u32, u32, u32, c_p, u64]),
+        "sh_dev_alloc": (i32, [c_p, u64, pp]),
+        "sh_dev_free": (i32, [c_p, c_p]),
+        "sh_dev_from_wire": (i32, [c_p, u8p, c_p, u64]),
+        "sh_dev_to_wire": (i32, [c_p, c_p, c_p, u64]),
+        "sh_dev_download": (i32, [c_p, c_p, c_p, u64]),
+        "sh_dev_upload": (i32, [c_p, u8p, c_p, u64]),
+        "sh_dev_fill_seeded": (i32, [c_p, c_p, u64, u64]),
+        "sh_dev_ntt": (i32, [c_p, c_p, c_p, u64, u32, u8p, i32]),
+        "sh_dev_merkelize": (i32, [c_p, c_p, u64, u32, c_p]),
+        "sh_dev_fri_fold": (i32, [c_p, c_p, c_p, u64, u32, u8p, c_p]),
+        "sh_dev_fri_prove": (i32, [c_p, c_p, u64, u8p, u64, u32, u32, u32, c_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the library does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    L._sig = sig
+    _lib = L
+    return L
+
+
+EXPORTED = None  # filled lazily by exported_symbols()
+
+
+def exported_symbols():
+    """Names bound above == every function include/starkhip.h declares (checked by tests)."""
+    return sorted(lib()._sig.keys())
+
+
+def default_device():
+    for var in ("STARKHIP_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+def ctx():
+    """The process-wide context (one process per GPU; device = $STARKHIP_DEVICE or $LOCAL_RANK or 0)."""
+    global _ctx
+    with _lock:
+        if _ctx is None:
+            L = lib()
+            h = ctypes.c_void_p()
+            rc = L.sh_ctx_create(default_device(), ctypes.byref(h))
+            if rc != 0:
+                raise StarkHipError(rc, "sh_ctx_create", "an MI355X (gfx950) GPU is required; there is no CPU fallback")
+            _ctx = h
+        return _ctx
+
+
+def close():
+    global _ctx
+    with _lock:
+        if _ctx is not None:
+            lib().sh_ctx_destroy(_ctx)
+            _ctx = None
+
+
+def check(rc, where):
+    if rc != 0:
+        detail = ""
+        if _ctx is not None:
+            detail = lib().sh_last_error(_ctx).decode()
+        raise StarkHipError(rc, where, detail)
+
+
+def to_wire(values, modulus=MIMC_P):
+    """list of ints / field elements -> concatenated 32-byte big-endian strings (modp.py:94-95).
+
+    Values already in [0, 2^256) are sent as they are (an element built from bytes may be unreduced,
+    modp.py:33-34; the device reduces); anything else is reduced first, as `field(int)` would."""
+    out = bytearray(32 * len(values))
+    lim = 1 << 256
+    for i, v in enumerate(values):
+        x = int(v)
+        if not 0 <= x < lim:
+            x %= modulus
+        out[32 * i:32 * i + 32] = x.to_bytes(32, "big")
+    return bytes(out)
+
+
+def from_wire(buf):
+    mv = memoryview(buf)
+    return [int.from_bytes(mv[i:i + 32], "big") for i in range(0, len(mv), 32)]
+
+
+def order_of_root(root, modulus=MIMC_P):
+    """Multiplicative order of `root` if it is a power of two <= 2^32 (the 2-adic part of p-1), else None.
+    The reference gets the same number by walking the powers until they return to 1 (fft.py:319-321)."""
+    t = int(root) % modulus
+    n = 1
+    for _ in range(33):
+        if t == 1:
+            return n
+        t = t * t % modulus
+        n *= 2
+    return None

@@ -1,0 +1,712 @@
+// capi.hip -- host side of libstarkhip.so: context, twiddle-table plans, the NTT / LDE / Merkle / FRI
+// drivers and the C ABI declared in include/starkhip.h.
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/starkhip.h"
+#include "internal.hpp"
+
+namespace {
+
+constexpr int DIRECT_TABLE_LOG = 16;  // power tables up to 2^16 entries (2 MiB) are stored in full
+
+// ---- host field helpers (the same fp256.cuh code the device runs) -----------------------------------
+fp h_from_wire(const uint8_t b[32]) {
+  uint32_t w[8];
+  memcpy(w, b, 32);
+  return fp_canon(fp_from_wire_words(w));
+}
+void h_to_wire(const fp& a, uint8_t b[32]) {
+  uint32_t w[8];
+  fp_to_wire_words(fp_canon(a), w);
+  memcpy(b, w, 32);
+}
+fp h_pow(fp a, uint64_t e) { return fp_pow_u64(a, e); }
+fp h_inv(const fp& a) {  // a^(p-2); modp.py:71-79 uses extended Euclid, the residue is the same
+  static const uint32_t e[8] = {0xffffffffu, 0xfffffea0u, 0xffffffffu, 0xffffffffu,
+                                0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};  // p - 2
+  fp r = fp_one(), b = a;
+  for (int i = 0; i < 256; ++i) {
+    if ((e[i / 32] >> (i % 32)) & 1) r = fp_mul(r, b);
+    b = fp_sqr(b);
+  }
+  return r;
+}
+int ilog2(uint64_t n) {
+  int k = 0;
+  while ((1ull << k) < n) ++k;
+  return k;
+}
+bool is_pow2(uint64_t n) { return n && !(n & (n - 1)); }
+
+// ---- plans ------------------------------------------------------------------------------------------
+struct PowTable {  // g^e for e < order: lo[e & mask] * hi[e >> lb]; hi == nullptr when stored in full
+  fp* lo = nullptr;
+  fp* hi = nullptr;
+  uint32_t lb = 0;
+};
+
+struct NttPlan {
+  uint64_t n = 0;
+  int log_n = 0;
+  bool scaled = false;       // multiply by n^-1 (inverse transform)
+  fp root;                   // effective root (already inverted for inverse transforms)
+  std::vector<int> radix;    // log2 radix of each pass
+  std::vector<fp*> wR;       // per pass: powers of root^(n/R), R/2 entries
+  std::vector<PowTable> tw;  // per column pass d: table of root^(P_d) (times n^-1 on pass 0 when scaled)
+  PowTable base;             // unscaled table of root (sh_power_cycle, FRI fold)
+  fp* scale = nullptr;       // n^-1 on the device (one-pass scaled plans)
+  std::vector<void*> owned;  // device allocations to free
+};
+
+}  // namespace
+
+struct sh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  std::map<std::string, NttPlan*> plans;
+  enum { WS_WIRE = 0, WS_X, WS_Y, WS_NTT, WS_TREE_A, WS_TREE_B, WS_COL_A, WS_COL_B, WS_MISC, WS_PROOF, WS_COUNT };
+  void* ws[WS_COUNT] = {};
+  size_t ws_cap[WS_COUNT] = {};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      char buf_[256];                                                                        \
+      snprintf(buf_, sizeof buf_, "%s at %s:%d", hipGetErrorString(e_), __FILE__, __LINE__); \
+      (ctx)->err = buf_;                                                                     \
+      return e_ == hipErrorOutOfMemory ? SH_ERR_NOMEM : SH_ERR_HIP;                          \
+    }                                                                                        \
+  } while (0)
+
+#define SH_TRY(expr)              \
+  do {                            \
+    int rc_ = (expr);             \
+    if (rc_ != SH_OK) return rc_; \
+  } while (0)
+
+int ws_get(sh_ctx* c, int slot, size_t bytes, void** out) {
+  if (bytes == 0) bytes = 32;
+  if (bytes > c->ws_cap[slot]) {
+    if (c->ws[slot]) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, hipFree(c->ws[slot]));
+      c->ws[slot] = nullptr;
+      c->ws_cap[slot] = 0;
+    }
+    size_t cap = (bytes + 4095) & ~(size_t)4095;
+    HIP_TRY(c, hipMalloc(&c->ws[slot], cap));
+    c->ws_cap[slot] = cap;
+  }
+  *out = c->ws[slot];
+  return SH_OK;
+}
+
+int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) {
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, host.size() * sizeof(fp)));
+  pl->owned.push_back(d);
+  HIP_TRY(c, hipMemcpy(d, host.data(), host.size() * sizeof(fp), hipMemcpyHostToDevice));
+  *dev = reinterpret_cast<fp*>(d);
+  return SH_OK;
+}
+
+// table of factor * g^e, e < 2^log_order (factor may be null)
+int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp* factor, PowTable* out) {
+  const bool direct = log_order <= DIRECT_TABLE_LOG;
+  const int lb = direct ? log_order : (log_order + 1) / 2;
+  std::vector<fp> lo((size_t)1 << lb);
+  lo[0] = fp_one();
+  for (size_t i = 1; i < lo.size(); ++i) lo[i] = fp_mul(lo[i - 1], g);
+  const fp gs = fp_mul(lo.back(), g);  // g^(2^lb)
+  if (direct && factor)
+    for (auto& v : lo) v = fp_mul(v, *factor);
+  SH_TRY(upload_table(c, pl, lo, &out->lo));
+  out->lb = (uint32_t)lb;
+  out->hi = nullptr;
+  if (!direct) {
+    std::vector<fp> hi((size_t)1 << (log_order - lb));
+    hi[0] = factor ? *factor : fp_one();
+    for (size_t i = 1; i < hi.size(); ++i) hi[i] = fp_mul(hi[i - 1], gs);
+    SH_TRY(upload_table(c, pl, hi, &out->hi));
+  }
+  return SH_OK;
+}
+
+void choose_radices(int log_n, std::vector<int>* out) {
+  out->clear();
+  if (log_n <= 8) {
+    out->push_back(log_n);
+    return;
+  }
+  const int m = (log_n + 7) / 8, base = log_n / m, rem = log_n % m;
+  for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));
+}
+
+std::string plan_key(const fp& root, uint64_t n, bool scaled) {
+  uint8_t b[32];
+  h_to_wire(root, b);
+  std::string k(reinterpret_cast<const char*>(b), 32);
+  k += std::to_string(n);
+  k += scaled ? "s" : "u";
+  return k;
+}
+
+// root must have order exactly n (a power of two): for n > 1 that is root^(n/2) == -1
+// (the reference finds n by walking the powers of the root, fft.py:319-321).
+int check_root_order(const fp& root, uint64_t n) {
+  if (n == 1) return fp_eq_canon(fp_canon(root), fp_one()) ? SH_OK : SH_ERR_ROOT_ORDER;
+  const fp h = fp_canon(h_pow(root, n / 2));
+  const fp m1 = fp_canon(fp_neg(fp_one()));
+  return fp_eq_canon(h, m1) ? SH_OK : SH_ERR_ROOT_ORDER;
+}
+
+int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** out) {
+  const std::string key = plan_key(root_eff, n, scaled);
+  auto it = c->plans.find(key);
+  if (it != c->plans.end()) {
+    *out = it->second;
+    return SH_OK;
+  }
+  NttPlan* pl = new NttPlan();
+  pl->n = n;
+  pl->log_n = ilog2(n);
+  pl->scaled = scaled;
+  pl->root = root_eff;
+  choose_radices(pl->log_n, &pl->radix);
+  const size_t m = pl->radix.size();
+  fp ninv = fp_one();
+  if (scaled) ninv = h_pow(h_inv(fp_from_u32(2u)), (uint64_t)pl->log_n);  // n^-1 = (2^-1)^log_n
+  int rc = build_pow_table(c, pl, root_eff, pl->log_n, nullptr, &pl->base);
+  if (rc == SH_OK && pl->log_n >= 2) {
+    std::map<int, fp*> wr_by_radix;
+    int log_P = 0;
+    for (size_t d = 0; d < m && rc == SH_OK; ++d) {
+      const int r = pl->radix[d];
+      if (!wr_by_radix.count(r)) {
+        const fp wr = h_pow(root_eff, n >> r);
+        std::vector<fp> t((size_t)1 << (r - 1));
+        t[0] = fp_one();
+        for (size_t i = 1; i < t.size(); ++i) t[i] = fp_mul(t[i - 1], wr);
+        fp* dev = nullptr;
+        rc = upload_table(c, pl, t, &dev);
+        wr_by_radix[r] = dev;
+      }
+      pl->wR.push_back(wr_by_radix[r]);
+      if (rc == SH_OK && d + 1 < m) {
+        PowTable t;
+        if (d == 0 && !scaled) {
+          t = pl->base;  // P_1 = 1: the table of the root itself
+        } else {
+          const fp g = h_pow(root_eff, 1ull << log_P);
+          rc = build_pow_table(c, pl, g, pl->log_n - log_P, (d == 0 && scaled) ? &ninv : nullptr, &t);
+        }
+        pl->tw.push_back(t);
+      }
+      log_P += r;
+    }
+  }
+  if (rc == SH_OK && scaled && m == 1) {
+    std::vector<fp> s(1, ninv);
+    rc = upload_table(c, pl, s, &pl->scale);
+  }
+  if (rc != SH_OK) {
+    for (void* p : pl->owned) (void)hipFree(p);
+    delete pl;
+    return rc;
+  }
+  c->plans[key] = pl;
+  *out = pl;
+  return SH_OK;
+}
+
+// d_out = NTT(d_in) over plan->root; [batch][n] limb form; d_in may equal d_out.
+int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch) {
+  const uint64_t n = pl->n;
+  if (batch == 0) return SH_OK;
+  if (pl->log_n <= 1) {
+    HIP_TRY(c, shk_launch_ntt_tiny(d_in, d_out, (uint32_t)n, batch, n == 2 ? pl->scale : nullptr, c->stream));
+    return SH_OK;
+  }
+  const size_t m = pl->radix.size();
+  const fp* src = d_in;
+  fp* work = d_out;
+  if (m > 1) {
+    void* w = nullptr;
+    SH_TRY(ws_get(c, sh_ctx::WS_NTT, (size_t)batch * n * sizeof(fp), &w));
+    work = reinterpret_cast<fp*>(w);
+  }
+  int log_P = 0;
+  for (size_t d = 0; d < m; ++d) {
+    const int r = pl->radix[d];
+    NttPassArgs a;
+    memset(&a, 0, sizeof a);
+    a.log_n = (uint32_t)pl->log_n;
+    a.wR = pl->wR[d];
+    const bool last = d + 1 == m;
+    if (!last) {
+      a.src = src;
+      a.dst = work;
+      a.log_S = (uint32_t)(pl->log_n - log_P - r);
+      a.total = (uint64_t)batch << (pl->log_n - r);  // batch * P * S columns
+      a.tw_lo = pl->tw[d].lo;
+      a.tw_hi = pl->tw[d].hi;
+      a.tw_lb = pl->tw[d].lb;
+      a.tw_direct = pl->tw[d].hi == nullptr;
+      src = work;
+    } else {
+      a.src = src;
+      a.dst = d_out;
+      a.log_P = (uint32_t)(pl->log_n - r);
+      a.total = (uint64_t)batch << a.log_P;  // rows
+      a.ndig = (uint32_t)(m - 1);
+      for (size_t k = 0; k + 1 < m; ++k) a.dig_log[k] = (uint32_t)pl->radix[k];
+      a.scale = (m == 1) ? pl->scale : nullptr;
+    }
+    HIP_TRY(c, shk_launch_ntt_pass(r, last, a, c->stream));
+    log_P += r;
+  }
+  return SH_OK;
+}
+
+int plan_for(sh_ctx* c, const uint8_t root[32], uint64_t n, bool inverse, NttPlan** out) {
+  if (!is_pow2(n) || n > (1ull << 32)) return n > (1ull << 32) ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
+  fp w = h_from_wire(root);
+  SH_TRY(check_root_order(w, n));
+  if (inverse) w = h_pow(w, n - 1);  // w^-1: the reversed root list rootz[:0:-1] of fft.py:327
+  return get_plan(c, w, n, inverse, out);
+}
+
+uint64_t fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
+  uint64_t total = 0;
+  bool first = true;
+  while (maxdeg_plus_1 > 16 && n >= 16) {
+    const uint64_t lg = (uint64_t)ilog2(n);
+    total += 32 + (uint64_t)(first ? samples : 40) * 32 * ((lg - 1) + 4 * (lg + 1));
+    n >>= 2;
+    maxdeg_plus_1 >>= 2;
+    first = false;
+  }
+  return total + 32 * n;
+}
+
+// FRI commit on device-resident coefficients; see starkhip.h for the layout.
+int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
+            uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* d_proof) {
+  if (!d_coeffs || !d_proof || batch == 0 || !is_pow2(n)) return SH_ERR_INVALID;
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, false, &pl));
+  // validate every round before launching anything
+  {
+    uint64_t nn = n, md = maxdeg_plus_1;
+    bool first = true;
+    while (md > 16) {
+      if (nn < 16) return SH_ERR_INVALID;            // the reference cannot merkelize a column of < 4 values
+      if ((nn >> 2) >= (1ull << 24)) return SH_ERR_UNSUPPORTED;  // assert modulus < 2**24 (utils.py:69)
+      const uint32_t s = first ? samples : 40;
+      if (s == 0) return SH_ERR_INVALID;
+      if (exclude == 1) return SH_ERR_INVALID;       // division by zero in the reference (utils.py:90)
+      if (exclude && ((nn >> 2) * (exclude - 1)) / exclude == 0) return SH_ERR_INVALID;
+      nn >>= 2;
+      md >>= 2;
+      first = false;
+    }
+  }
+  const uint64_t stride = fri_proof_len(n, maxdeg_plus_1, samples);
+  void *va, *vb, *ta, *tb, *misc;
+  SH_TRY(ws_get(c, sh_ctx::WS_COL_A, (size_t)batch * n * sizeof(fp), &va));
+  SH_TRY(ws_get(c, sh_ctx::WS_COL_B, (size_t)batch * (n / 4 + 1) * sizeof(fp), &vb));
+  SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)batch * 2 * n * 32, &ta));
+  SH_TRY(ws_get(c, sh_ctx::WS_TREE_B, (size_t)batch * 2 * (n / 4 + 1) * 32, &tb));
+  SH_TRY(ws_get(c, sh_ctx::WS_MISC, (size_t)batch * (samples > 40 ? samples : 40) * 4 + 64, &misc));
+  fp* vals = reinterpret_cast<fp*>(va);
+  fp* next = reinterpret_cast<fp*>(vb);
+  uint32_t* tree = reinterpret_cast<uint32_t*>(ta);
+  uint32_t* tree2 = reinterpret_cast<uint32_t*>(tb);
+  // values = fft(f) over the whole domain (fri.py:207-208)
+  SH_TRY(run_ntt(c, pl, d_coeffs, vals, batch));
+  uint64_t nn = n, md = maxdeg_plus_1, off = 0;
+  uint32_t round = 0;
+  const fp inv_i = h_pow(pl->root, 3 * (n / 4));  // I^-1 = I^3, I = root^(n/4)
+  const fp inv_4 = h_inv(fp_from_u32(4u));
+  bool have_tree = false;
+  while (md > 16) {
+    const uint32_t s = round == 0 ? samples : 40;
+    if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream));  // m = merkelize(values), fri.py:224
+    FoldArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.values = vals;
+    fa.nodes = tree;
+    fa.column = next;
+    fa.n = nn;
+    fa.batch = batch;
+    fa.tw_lo = pl->base.lo;
+    fa.tw_hi = pl->base.hi;
+    fa.tw_lb = pl->base.lb;
+    fa.log_n0 = (uint32_t)pl->log_n;
+    fa.round_shift = 2 * round;
+    fa.inv_i = inv_i;
+    fa.inv_4 = inv_4;
+    HIP_TRY(c, shk_fri_fold(fa, c->stream));                                   // column, fri.py:235-242
+    HIP_TRY(c, shk_merkelize(next, false, nn / 4, batch, tree2, c->stream));   // m2, fri.py:243
+    SampleArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.nodes_m = tree;
+    sa.nodes_m2 = tree2;
+    sa.n = nn;
+    sa.batch = batch;
+    sa.samples = s;
+    sa.exclude = exclude;
+    sa.ys = reinterpret_cast<uint32_t*>(misc);
+    sa.proof = d_proof;
+    sa.proof_stride = stride;
+    sa.round_off = off;
+    HIP_TRY(c, shk_fri_sample_and_gather(sa, c->stream));                      // fri.py:246-254
+    const uint64_t lg = (uint64_t)ilog2(nn);
+    off += 32 + (uint64_t)s * 32 * ((lg - 1) + 4 * (lg + 1));
+    // Next round (fri.py:260-266): the reference inverse-transforms the column over root^4 and transforms it
+    // back, which is the identity on the column; its tree m of round r+1 is this round's m2.
+    std::swap(vals, next);
+    std::swap(tree, tree2);
+    have_tree = true;
+    nn >>= 2;
+    md >>= 2;
+    ++round;
+  }
+  HIP_TRY(c, shk_fri_final(vals, nn, batch, d_proof, stride, off, c->stream));  // fri.py:212-214
+  return SH_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+const char* sh_strerror(int status) {
+  switch (status) {
+    case SH_OK: return "ok";
+    case SH_ERR_INVALID: return "invalid argument";
+    case SH_ERR_ROOT_ORDER: return "root_of_unity does not have order n";
+    case SH_ERR_HIP: return "HIP runtime error";
+    case SH_ERR_NOMEM: return "out of memory";
+    case SH_ERR_TOO_SMALL: return "output buffer too small";
+    case SH_ERR_UNSUPPORTED: return "unsupported size";
+    case SH_ERR_NO_DEVICE: return "no usable gfx950 device";
+    default: return "unknown status";
+  }
+}
+const char* sh_version(void) { return "starkhip 0.1 (gfx950)"; }
+
+int sh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sh_ctx_create(int device, sh_ctx** out) {
+  if (!out) return SH_ERR_INVALID;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SH_ERR_NO_DEVICE;
+  sh_ctx* c = new sh_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return SH_ERR_HIP;
+  }
+  *out = c;
+  return SH_OK;
+}
+
+void sh_ctx_destroy(sh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->plans) {
+    for (void* p : kv.second->owned) (void)hipFree(p);
+    delete kv.second;
+  }
+  for (int i = 0; i < sh_ctx::WS_COUNT; ++i)
+    if (c->ws[i]) (void)hipFree(c->ws[i]);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* sh_last_error(const sh_ctx* c) { return c ? c->err.c_str() : ""; }
+
+int sh_sync(sh_ctx* c) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+int sh_timer_start(sh_ctx* c) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  return SH_OK;
+}
+int sh_timer_stop(sh_ctx* c, float* ms) {
+  if (!c || !ms) return SH_ERR_INVALID;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->ev1));
+  HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return SH_OK;
+}
+
+// ---- device-resident API ------------------------------------------------------------------------------
+int sh_dev_alloc(sh_ctx* c, uint64_t bytes, void** dptr) {
+  if (!c || !dptr) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMalloc(dptr, bytes ? bytes : 32));
+  return SH_OK;
+}
+int sh_dev_free(sh_ctx* c, void* dptr) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipFree(dptr));
+  return SH_OK;
+}
+int sh_dev_upload(sh_ctx* c, const void* host_src, void* d_dst, uint64_t bytes) {
+  if (!c || (!host_src && bytes) || (!d_dst && bytes)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+int sh_dev_download(sh_ctx* c, const void* d_src, void* host_dst, uint64_t bytes) {
+  if (!c || (!host_dst && bytes) || (!d_src && bytes)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+int sh_dev_from_wire(sh_ctx* c, const uint8_t* host_wire, void* d_limbs, uint64_t n) {
+  if (!c || (n && (!host_wire || !d_limbs))) return SH_ERR_INVALID;
+  void* w = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, n * 32, &w));
+  HIP_TRY(c, hipMemcpyAsync(w, host_wire, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<const uint8_t*>(w), reinterpret_cast<fp*>(d_limbs), n, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+int sh_dev_to_wire(sh_ctx* c, const void* d_limbs, uint8_t* host_wire, uint64_t n) {
+  if (!c || (n && (!host_wire || !d_limbs))) return SH_ERR_INVALID;
+  void* w = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, n * 32, &w));
+  HIP_TRY(c, shk_limb_to_wire(reinterpret_cast<const fp*>(d_limbs), reinterpret_cast<uint8_t*>(w), n, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(host_wire, w, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+int sh_dev_fill_seeded(sh_ctx* c, void* d_limbs, uint64_t n, uint64_t seed) {
+  if (!c || (n && !d_limbs)) return SH_ERR_INVALID;
+  HIP_TRY(c, shk_fill_seeded(reinterpret_cast<fp*>(d_limbs), n, seed, c->stream));
+  return SH_OK;
+}
+int sh_dev_ntt(sh_ctx* c, const void* d_in, void* d_out, uint64_t n, uint32_t batch, const uint8_t root[32],
+               int inverse) {
+  if (!c || !d_in || !d_out || !root) return SH_ERR_INVALID;
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
+  return run_ntt(c, pl, reinterpret_cast<const fp*>(d_in), reinterpret_cast<fp*>(d_out), batch);
+}
+int sh_dev_merkelize(sh_ctx* c, const void* d_values, uint64_t n, uint32_t batch, void* d_nodes) {
+  if (!c || !d_values || !d_nodes || !is_pow2(n) || n < 4 || batch == 0) return SH_ERR_INVALID;
+  HIP_TRY(c, shk_merkelize(d_values, false, n, batch, reinterpret_cast<uint32_t*>(d_nodes), c->stream));
+  return SH_OK;
+}
+int sh_dev_fri_fold(sh_ctx* c, const void* d_values, const void* d_nodes, uint64_t n, uint32_t batch,
+                    const uint8_t root[32], void* d_column) {
+  if (!c || !d_values || !d_nodes || !d_column || !root || n < 4) return SH_ERR_INVALID;
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, false, &pl));
+  FoldArgs fa;
+  memset(&fa, 0, sizeof fa);
+  fa.values = reinterpret_cast<const fp*>(d_values);
+  fa.nodes = reinterpret_cast<const uint32_t*>(d_nodes);
+  fa.column = reinterpret_cast<fp*>(d_column);
+  fa.n = n;
+  fa.batch = batch;
+  fa.tw_lo = pl->base.lo;
+  fa.tw_hi = pl->base.hi;
+  fa.tw_lb = pl->base.lb;
+  fa.log_n0 = (uint32_t)pl->log_n;
+  fa.round_shift = 0;
+  fa.inv_i = h_pow(pl->root, 3 * (n / 4));
+  fa.inv_4 = h_inv(fp_from_u32(4u));
+  HIP_TRY(c, shk_fri_fold(fa, c->stream));
+  return SH_OK;
+}
+int sh_dev_fri_prove(sh_ctx* c, const void* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
+                     uint32_t exclude, uint32_t samples, uint32_t batch, void* d_proof) {
+  if (!c || !root) return SH_ERR_INVALID;
+  return run_fri(c, reinterpret_cast<const fp*>(d_coeffs), n, root, maxdeg_plus_1, exclude, samples, batch,
+                 reinterpret_cast<uint8_t*>(d_proof));
+}
+
+// ---- host-buffer API --------------------------------------------------------------------------------
+static int upload_padded(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint64_t n, uint32_t batch, int slot, fp** out) {
+  void *w = nullptr, *x = nullptr, *y = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)batch * (n_in > n ? n_in : n) * 32, &w));
+  SH_TRY(ws_get(c, slot, (size_t)batch * n * sizeof(fp), &x));
+  if (n_in == n) {
+    HIP_TRY(c, hipMemcpyAsync(w, in, (size_t)batch * n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<uint8_t*>(w), reinterpret_cast<fp*>(x), (uint64_t)batch * n, c->stream));
+  } else {
+    SH_TRY(ws_get(c, sh_ctx::WS_MISC, (size_t)batch * (n_in ? n_in : 1) * sizeof(fp), &y));
+    if (n_in) {
+      HIP_TRY(c, hipMemcpyAsync(w, in, (size_t)batch * n_in * 32, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<uint8_t*>(w), reinterpret_cast<fp*>(y), (uint64_t)batch * n_in, c->stream));
+    }
+    HIP_TRY(c, shk_pad_copy(reinterpret_cast<fp*>(y), reinterpret_cast<fp*>(x), n_in, n, batch, c->stream));  // fft.py:323-324
+  }
+  *out = reinterpret_cast<fp*>(x);
+  return SH_OK;
+}
+static int download_wire(sh_ctx* c, const fp* d, uint8_t* out, uint64_t count) {
+  void* w = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)count * 32, &w));
+  HIP_TRY(c, shk_limb_to_wire(d, reinterpret_cast<uint8_t*>(w), count, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(out, w, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
+int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t n, uint32_t batch,
+                 const uint8_t root[32], int inverse) {
+  if (!c || !out || !root || (n_in && !in) || batch == 0) return SH_ERR_INVALID;
+  if (n_in > n) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
+  fp* x = nullptr;
+  SH_TRY(upload_padded(c, in, n_in, n, batch, sh_ctx::WS_X, &x));
+  SH_TRY(run_ntt(c, pl, x, x, batch));
+  return download_wire(c, x, out, (uint64_t)batch * n);
+}
+int sh_ntt(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t n, const uint8_t root[32], int inverse) {
+  return sh_ntt_batch(c, in, n_in, out, n, 1, root, inverse);
+}
+
+int sh_mul_polys(sh_ctx* c, const uint8_t* a, uint64_t n_a, const uint8_t* b, uint64_t n_b, uint8_t* out, uint64_t n,
+                 const uint8_t root[32]) {
+  if (!c || !out || !root || (n_a && !a) || (n_b && !b) || n_a > n || n_b > n) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  NttPlan *fwd = nullptr, *rev = nullptr;
+  SH_TRY(plan_for(c, root, n, false, &fwd));
+  SH_TRY(get_plan(c, h_pow(fwd->root, n - 1), n, false, &rev));  // reversed roots, NO 1/n (fft.py:345)
+  fp *x = nullptr, *y = nullptr;
+  SH_TRY(upload_padded(c, a, n_a, n, 1, sh_ctx::WS_X, &x));
+  SH_TRY(upload_padded(c, b, n_b, n, 1, sh_ctx::WS_Y, &y));
+  SH_TRY(run_ntt(c, fwd, x, x, 1));
+  SH_TRY(run_ntt(c, fwd, y, y, 1));
+  HIP_TRY(c, shk_pointwise_mul(x, y, x, n, c->stream));
+  SH_TRY(run_ntt(c, rev, x, x, 1));
+  return download_wire(c, x, out, n);
+}
+
+int sh_power_cycle(sh_ctx* c, const uint8_t root[32], uint64_t n, uint8_t* out) {
+  if (!c || !out || !root) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, false, &pl));
+  void* x = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_X, (size_t)n * sizeof(fp), &x));
+  HIP_TRY(c, shk_powers(pl->base.lo, pl->base.hi, pl->base.lb, reinterpret_cast<fp*>(x), n, c->stream));
+  return download_wire(c, reinterpret_cast<fp*>(x), out, n);
+}
+
+int sh_lde(sh_ctx* c, const uint8_t* trace, uint8_t* out, uint64_t steps, uint32_t ext, uint32_t cols,
+           const uint8_t g2[32]) {
+  if (!c || !trace || !out || !g2 || cols == 0 || !is_pow2(steps) || !is_pow2(ext)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t n = steps * ext;
+  NttPlan *inv1 = nullptr, *fwd2 = nullptr;
+  SH_TRY(plan_for(c, g2, n, false, &fwd2));
+  uint8_t g1b[32];
+  h_to_wire(h_pow(fwd2->root, ext), g1b);  // G1 = G2^ext (stark.py:217-220)
+  SH_TRY(plan_for(c, g1b, steps, true, &inv1));
+  fp* t = nullptr;
+  SH_TRY(upload_padded(c, trace, steps, steps, cols, sh_ctx::WS_Y, &t));
+  SH_TRY(run_ntt(c, inv1, t, t, cols));  // trace polynomial coefficients (stark.py:27-36)
+  void* x = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_X, (size_t)cols * n * sizeof(fp), &x));
+  HIP_TRY(c, shk_pad_copy(t, reinterpret_cast<fp*>(x), steps, n, cols, c->stream));
+  SH_TRY(run_ntt(c, fwd2, reinterpret_cast<fp*>(x), reinterpret_cast<fp*>(x), cols));  // stark.py:253-256
+  return download_wire(c, reinterpret_cast<fp*>(x), out, (uint64_t)cols * n);
+}
+
+int sh_merkelize(sh_ctx* c, const uint8_t* leaves, uint64_t n, uint8_t* nodes) {
+  if (!c || !leaves || !nodes || !is_pow2(n) || n < 4) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  void *w = nullptr, *t = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)n * 32, &w));
+  SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)2 * n * 32, &t));
+  HIP_TRY(c, hipMemcpyAsync(w, leaves, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, shk_merkelize(w, true, n, 1, reinterpret_cast<uint32_t*>(t), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(nodes, t, (size_t)2 * n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
+int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root[32], const uint8_t special_x[32],
+                uint8_t* column) {
+  if (!c || !values || !root || !special_x || !column || !is_pow2(n) || n < 4) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, false, &pl));
+  fp* v = nullptr;
+  SH_TRY(upload_padded(c, values, n, n, 1, sh_ctx::WS_X, &v));
+  void *col = nullptr, *sx = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_COL_B, (size_t)(n / 4) * sizeof(fp), &col));
+  SH_TRY(ws_get(c, sh_ctx::WS_MISC, 64, &sx));
+  HIP_TRY(c, hipMemcpyAsync(sx, special_x, 32, hipMemcpyHostToDevice, c->stream));
+  FoldArgs fa;
+  memset(&fa, 0, sizeof fa);
+  fa.values = v;
+  fa.nodes = nullptr;
+  fa.special_x = reinterpret_cast<const uint32_t*>(sx);
+  fa.column = reinterpret_cast<fp*>(col);
+  fa.n = n;
+  fa.batch = 1;
+  fa.tw_lo = pl->base.lo;
+  fa.tw_hi = pl->base.hi;
+  fa.tw_lb = pl->base.lb;
+  fa.log_n0 = (uint32_t)pl->log_n;
+  fa.inv_i = h_pow(pl->root, 3 * (n / 4));
+  fa.inv_4 = h_inv(fp_from_u32(4u));
+  HIP_TRY(c, shk_fri_fold(fa, c->stream));
+  return download_wire(c, reinterpret_cast<fp*>(col), column, n / 4);
+}
+
+uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
+  return fri_proof_len(n, maxdeg_plus_1, samples);
+}
+
+int sh_fri_prove(sh_ctx* c, const uint8_t* coeffs, uint64_t n_coeffs, uint64_t n, const uint8_t root[32],
+                 uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* proof,
+                 uint64_t proof_cap) {
+  if (!c || !root || !proof || (n_coeffs && !coeffs) || batch == 0 || n_coeffs > n || !is_pow2(n)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t stride = fri_proof_len(n, maxdeg_plus_1, samples);
+  if (proof_cap < stride * batch) return SH_ERR_TOO_SMALL;
+  fp* x = nullptr;
+  SH_TRY(upload_padded(c, coeffs, n_coeffs, n, batch, sh_ctx::WS_X, &x));
+  void* dp = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_PROOF, (size_t)stride * batch, &dp));
+  SH_TRY(run_fri(c, x, n, root, maxdeg_plus_1, exclude, samples, batch, reinterpret_cast<uint8_t*>(dp)));
+  HIP_TRY(c, hipMemcpyAsync(proof, dp, (size_t)stride * batch, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
+}  // extern "C"

@@ -226,3 +226,19 @@ FP_HD void fp_to_wire_words(const fp& a, uint32_t w[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) w[i] = fp_bswap32(a.v[7 - i]);
 }
+
+// ---- 32-byte element loads/stores (two dwordx4 per lane) ------------------------------------------
+__device__ __forceinline__ fp fp_load(const fp* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  fp r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void fp_store(fp* p, const fp& r) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+

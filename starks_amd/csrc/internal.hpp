@@ -1,0 +1,79 @@
+// internal.hpp -- declarations shared by the translation units of libstarkhip.so (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fp256.cuh"
+
+struct NttPassArgs {
+  const fp* src;
+  fp* dst;
+  uint64_t total;     // number of columns (column pass: batch*P*S) or rows (row pass: batch*P)
+  uint32_t log_n;     // log2 of the transform length
+  uint32_t log_S;     // column pass: log2 stride between successive points of a column
+  uint32_t log_P;     // row pass: log2 number of rows per transform (n / R)
+  const fp* wR;       // w^(n/R * k), k < R/2
+  // column pass: table of g = w^P, order R*S:  g^e = lo[e & mask] (* hi[e >> lb] unless direct)
+  const fp* tw_lo;
+  const fp* tw_hi;
+  uint32_t tw_lb;
+  uint32_t tw_direct;
+  // row pass: radix logs of the earlier passes (digits k_1 .. k_{m-1} of the row number, k_1 first)
+  uint32_t ndig;
+  uint32_t dig_log[3];
+  const fp* scale;    // row pass: optional factor applied to every output (n^-1 of a one-pass inverse)
+};
+
+// ---- ntt.hip ----------------------------------------------------------------------------------
+// Launch one tile pass (radix 2^log_R).  Returns hipSuccess or the launch error.
+hipError_t shk_launch_ntt_pass(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
+hipError_t shk_launch_ntt_tiny(const fp* src, fp* dst, uint32_t n, uint32_t batch, const fp* scale, hipStream_t st);
+constexpr int SHK_TILE_LOG = 11;  // 2048 elements (64 KiB of LDS) per workgroup
+
+// ---- kernels.hip: conversions, powers, Merkle, FRI fold, sampling, branch gather ------------------
+hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st);
+hipError_t shk_limb_to_wire(const fp* d_limbs, uint8_t* d_wire, uint64_t n, hipStream_t st);
+hipError_t shk_fill_seeded(fp* d, uint64_t n, uint64_t seed, hipStream_t st);
+hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipStream_t st);
+// out[i] = g^i for i < n, g given by its two-level table (lo, hi, lb)
+hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st);
+// zero-pad: dst[b][0..n_in) = src[b][0..n_in), dst[b][n_in..n) = 0
+hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st);
+// dst[b][ext*i] = src[b][i] ... not used: LDE pads coefficients, see capi
+// Merkle tree of `batch` arrays of n limb-form values (or n raw 32-byte leaves when raw_leaves).
+hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
+                         hipStream_t st);
+struct FoldArgs {
+  const fp* values;        // [batch][n]
+  const uint32_t* nodes;   // [batch][2n][8 words]; challenge = node 1 (nullptr: use special_x)
+  const uint32_t* special_x;  // 8 wire words (used when nodes == nullptr)
+  fp* column;              // [batch][n/4]
+  uint64_t n;
+  uint32_t batch;
+  // powers of the ROUND-0 generator w0 (order n0): w0^e = lo[e & mask] * hi[e >> lb]
+  const fp* tw_lo;
+  const fp* tw_hi;
+  uint32_t tw_lb;
+  uint32_t log_n0;
+  uint32_t round_shift;    // this round's generator is w0^(2^round_shift)
+  fp inv_i;                // (w0^(n0/4))^-1: inverse of the primitive 4th root of unity
+  fp inv_4;                // 4^-1
+};
+hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st);
+// ys[b][s] from the column tree's root (utils.py:60-90), then copy 5 branches per sample into the proof
+struct SampleArgs {
+  const uint32_t* nodes_m;   // [batch][2n][8]   tree of the values
+  const uint32_t* nodes_m2;  // [batch][2q][8]   tree of the column (q = n/4)
+  uint64_t n;
+  uint32_t batch;
+  uint32_t samples;
+  uint32_t exclude;
+  uint32_t* ys;              // [batch][samples] scratch
+  uint8_t* proof;            // [batch][proof_stride] device proof buffers
+  uint64_t proof_stride;
+  uint64_t round_off;        // byte offset of this round inside a proof
+};
+hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st);
+// final layer: canonical wire form of values[b][0..n) into proof[b] + off
+hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,
+                         uint64_t off, hipStream_t st);

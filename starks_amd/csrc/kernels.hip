@@ -1,0 +1,354 @@
+// kernels.hip -- the non-NTT kernels of the FRI commit path: wire<->limb conversion, synthetic input,
+// BLAKE2s Merkle tree (merkle_tree.py:36-56), FRI fold (fri.py:235-242), query sampling (utils.py:60-90)
+// and Merkle branch gather (merkle_tree.py:59-68).
+#include "blake2s.cuh"
+#include "internal.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline unsigned grid_for(uint64_t work, int tpb = TPB) { return (unsigned)((work + tpb - 1) / tpb); }
+
+__device__ __forceinline__ void load8(const uint32_t* p, uint32_t w[8]) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint32_t* p, const uint32_t w[8]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// ---- conversions ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TPB) wire_to_limb_kernel(const uint32_t* wire, fp* limbs, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  load8(wire + 8 * i, w);
+  fp_store(limbs + i, fp_from_wire_words(w));  // may be >= p: limb form is lazily reduced
+}
+__global__ void __launch_bounds__(TPB) limb_to_wire_kernel(const fp* limbs, uint32_t* wire, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  fp_to_wire_words(fp_canon(fp_load(limbs + i)), w);
+  store8(wire + 8 * i, w);
+}
+// x_i = BLAKE2s(seed_le64 || i_le64) mod p   (same generator as tests/golden/generate.py)
+__global__ void __launch_bounds__(TPB) fill_seeded_kernel(fp* out, uint64_t n, uint64_t seed) {
+  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  uint32_t m[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] = 0;
+  m[0] = (uint32_t)seed;
+  m[1] = (uint32_t)(seed >> 32);
+  m[2] = (uint32_t)i;
+  m[3] = (uint32_t)(i >> 32);
+  b2digest d = b2_hash_short(m, 16);
+  fp_store(out + i, fp_canon(fp_from_wire_words(d.h)));
+}
+__global__ void __launch_bounds__(TPB) pointwise_mul_kernel(const fp* a, const fp* b, fp* out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  fp_store(out + i, fp_mul(fp_load(a + i), fp_load(b + i)));
+}
+__global__ void __launch_bounds__(TPB) powers_kernel(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  fp v = fp_load(lo + (i & ((1ull << lb) - 1)));
+  if (hi) v = fp_mul(v, fp_load(hi + (i >> lb)));
+  fp_store(out + i, v);
+}
+__global__ void __launch_bounds__(TPB) pad_copy_kernel(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint64_t total) {
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= total) return;
+  uint64_t b = g / n, i = g - b * n;
+  fp_store(dst + g, i < n_in ? fp_load(src + b * n_in + i) : fp_zero());
+}
+
+// ---- Merkle tree ------------------------------------------------------------------------------------
+// One thread per row i of permute4 (merkle_tree.py:11-23): writes the 4 leaves 4i..4i+3 (wire form) and
+// the three nodes above them.
+template <bool RAW>
+__global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, uint64_t n, uint32_t batch, uint32_t* nodes) {
+  const uint64_t q = n >> 2;
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= q * batch) return;
+  const uint64_t b = g / q, i = g - b * q;
+  uint32_t* tree = nodes + b * (2 * n) * 8;
+  uint32_t w[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (RAW) {
+      load8(reinterpret_cast<const uint32_t*>(leaves) + (b * n + i + j * q) * 8, w[j]);
+    } else {
+      fp v = fp_canon(fp_load(reinterpret_cast<const fp*>(leaves) + b * n + i + j * q));
+      fp_to_wire_words(v, w[j]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
+    }
+    store8(tree + (n + 4 * i + j) * 8, w[j]);
+  }
+  b2digest d0 = b2_hash_pair(w[0], w[1]);
+  b2digest d1 = b2_hash_pair(w[2], w[3]);
+  store8(tree + (n / 2 + 2 * i) * 8, d0.h);
+  store8(tree + (n / 2 + 2 * i + 1) * 8, d1.h);
+  b2digest d2 = b2_hash_pair(d0.h, d1.h);
+  store8(tree + (n / 4 + i) * 8, d2.h);
+  if (i == 0) {
+    uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    store8(tree, z);  // nodes[0]: the reference keeps b'' there
+  }
+}
+
+// Reduces 512 nodes of level L to one node of level L-9, writing every level on the way:
+// one hash per thread from global memory, six levels inside each wavefront through lane shuffles
+// (the per-wave Merkle-pair reduction), the last two through LDS.
+__global__ void __launch_bounds__(TPB) merkle_upper_kernel(uint32_t* nodes, uint64_t n, uint32_t L) {
+  __shared__ uint32_t wave_out[4][8];
+  uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t lvl = L - 1;
+  uint64_t idx = (uint64_t)blockIdx.x * TPB + tid;
+  b2digest d;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d.h[k] = 0;
+  if (idx < (1ull << lvl)) {
+    uint32_t l[8], r[8];
+    load8(tree + ((1ull << L) + 2 * idx) * 8, l);
+    load8(tree + ((1ull << L) + 2 * idx + 1) * 8, r);
+    d = b2_hash_pair(l, r);
+    store8(tree + ((1ull << lvl) + idx) * 8, d.h);
+  }
+  // in-wave levels
+  uint64_t wbase = (uint64_t)blockIdx.x * TPB + wave * 64;  // node index of lane 0 at the current level
+#pragma unroll
+  for (int s = 1; s <= 6; ++s) {
+    if (lvl == 0) break;
+    lvl -= 1;
+    wbase >>= 1;
+    uint32_t l[8], r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      l[k] = __shfl(d.h[k], (int)((2 * lane) & 63));
+      r[k] = __shfl(d.h[k], (int)((2 * lane + 1) & 63));
+    }
+    if (lane < (64u >> s) && wbase + lane < (1ull << lvl)) {
+      d = b2_hash_pair(l, r);
+      store8(tree + ((1ull << lvl) + wbase + lane) * 8, d.h);
+    }
+  }
+  if (lvl == 0) return;  // uniform per block: all lanes see the same lvl
+  // across the 4 waves
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wave_out[wave][k] = d.h[k];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  lvl -= 1;  // level L-8: two nodes per block
+  uint64_t bbase = (uint64_t)blockIdx.x * 2;
+  if (lane < 2 && bbase + lane < (1ull << lvl)) {
+    d = b2_hash_pair(wave_out[2 * lane], wave_out[2 * lane + 1]);
+    store8(tree + ((1ull << lvl) + bbase + lane) * 8, d.h);
+  }
+  if (lvl == 0) return;
+  lvl -= 1;  // level L-9: one node per block
+  uint32_t r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[k] = __shfl(d.h[k], 1);
+  if (lane == 0 && blockIdx.x < (1ull << lvl)) {
+    b2digest e = b2_hash_pair(d.h, r);
+    store8(tree + ((1ull << lvl) + blockIdx.x) * 8, e.h);
+  }
+}
+
+// ---- FRI fold ---------------------------------------------------------------------------------------
+// column[i] = P_i(x*), P_i the cubic through (x_i I^j, v_j), v_j = values[i + j q], x_i = w^i, I = w^q.
+// With g = 1/4 * iDFT_4(v) (w.r.t. I) the cubic is sum_k g_k (x / x_i)^k, so
+//   column[i] = 1/4 * (G0 + G1 t + G2 t^2 + G3 t^3),   t = x* / x_i = x* * w^(-i),
+//   G0 = u0 + u2, G2 = u0 - u2, G1 = u1 + u3, G3 = u1 - u3,
+//   u0 = v0 + v2, u1 = v0 - v2, u2 = v1 + v3, u3 = (v1 - v3) / I.
+// Residues are unique, so this equals the reference's Lagrange route (poly_utils.py:412-440) bit for bit.
+__global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
+  const uint64_t q = a.n >> 2;
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= q * a.batch) return;
+  const uint64_t b = g / q, i = g - b * q;
+  uint32_t sxw[8];
+  if (a.nodes) {
+    load8(a.nodes + (b * 2 * a.n + 1) * 8, sxw);  // special_x = field(m[1]) (fri.py:229), unreduced bytes
+  } else {
+    load8(a.special_x, sxw);
+  }
+  const fp sx = fp_from_wire_words(sxw);
+  const fp* v = a.values + b * a.n + i;
+  const fp v0 = fp_load(v), v1 = fp_load(v + q), v2 = fp_load(v + 2 * q), v3 = fp_load(v + 3 * q);
+  // w_r^(-i) = w0^(n0 - i * 2^shift)
+  const uint64_t n0m = (1ull << a.log_n0) - 1;
+  const uint64_t e = ((1ull << a.log_n0) - ((i << a.round_shift) & n0m)) & n0m;
+  fp winv = fp_load(a.tw_lo + (e & ((1ull << a.tw_lb) - 1)));
+  if (a.tw_hi) winv = fp_mul(winv, fp_load(a.tw_hi + (e >> a.tw_lb)));
+  const fp t = fp_mul(sx, winv);
+  const fp u0 = fp_add(v0, v2), u1 = fp_sub(v0, v2), u2 = fp_add(v1, v3);
+  const fp u3 = fp_mul(fp_sub(v1, v3), a.inv_i);
+  const fp G0 = fp_add(u0, u2), G2 = fp_sub(u0, u2), G1 = fp_add(u1, u3), G3 = fp_sub(u1, u3);
+  fp acc = fp_add(fp_mul(G3, t), G2);
+  acc = fp_add(fp_mul(acc, t), G1);
+  acc = fp_add(fp_mul(acc, t), G0);
+  fp_store(a.column + b * q + i, fp_mul(acc, a.inv_4));
+}
+
+// ---- query sampling + branch gather --------------------------------------------------------------------
+// get_pseudorandom_indices(m2[1], q, samples, exclude_multiples_of) (utils.py:60-90), one thread per proof.
+__global__ void fri_sample_kernel(SampleArgs a) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  const uint64_t q = a.n >> 2;
+  uint32_t blk[16];
+  load8(a.nodes_m2 + ((uint64_t)b * 2 * q + 1) * 8, blk);  // entropy = root of the column tree
+#pragma unroll
+  for (int k = 8; k < 16; ++k) blk[k] = 0;
+  const uint32_t modulus = (uint32_t)q;
+  const uint32_t real = a.exclude ? (uint32_t)(((uint64_t)modulus * (a.exclude - 1)) / a.exclude) : modulus;
+  uint32_t* ys = a.ys + (uint64_t)b * a.samples;
+  for (uint32_t j = 0; j < a.samples; ++j) {
+    if (j && (j & 7) == 0) {  // data += blake(data[-32:])  (utils.py:74-75)
+      b2digest d = b2_hash_short(blk, 32);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) blk[k] = d.h[k];
+    }
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((j & 7) == (uint32_t)k) word = blk[k];
+    const uint32_t x = __builtin_bswap32(word) % real;  // int.from_bytes(data[i:i+4], 'big') % modulus
+    ys[j] = a.exclude ? x + 1 + x / (a.exclude - 1) : x;
+  }
+}
+// mk_branch (merkle_tree.py:59-68) for the 5 branches of every sample, written into the flat proof.
+__global__ void __launch_bounds__(TPB) fri_gather_kernel(SampleArgs a, uint32_t l1, uint32_t l2) {
+  const uint64_t q = a.n >> 2;
+  const uint32_t per_sample = l2 + 4 * l1;
+  const uint64_t per_proof = (uint64_t)a.samples * per_sample + 1;  // +1: the root2 slot
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= per_proof * a.batch) return;
+  const uint64_t b = g / per_proof;
+  uint64_t r = g - b * per_proof;
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.proof + b * a.proof_stride + a.round_off);
+  const uint32_t* m = a.nodes_m + b * 2 * a.n * 8;
+  const uint32_t* m2 = a.nodes_m2 + b * 2 * q * 8;
+  uint32_t w[8];
+  if (r == 0) {
+    load8(m2 + 8, w);
+    store8(out, w);
+    return;
+  }
+  r -= 1;
+  const uint32_t s = (uint32_t)(r / per_sample), slot = (uint32_t)(r - (uint64_t)s * per_sample);
+  const uint32_t y = a.ys[b * a.samples + s];
+  const uint32_t* tree;
+  uint64_t leaves, index;
+  uint32_t lev;
+  if (slot < l2) {
+    tree = m2; leaves = q; index = y; lev = slot;
+  } else {
+    const uint32_t br = (slot - l2) / l1;
+    tree = m; leaves = a.n; index = y + q * br; lev = (slot - l2) - br * l1;
+  }
+  const uint64_t ld4 = leaves >> 2;  // get_index_in_permuted (merkle_tree.py:26-33)
+  uint64_t idx = index / ld4 + 4 * (index % ld4) + leaves;
+  const uint64_t node = lev == 0 ? idx : ((idx >> (lev - 1)) ^ 1);
+  load8(tree + node * 8, w);
+  store8(out + 8 + ((uint64_t)s * per_sample + slot) * 8, w);
+}
+__global__ void __launch_bounds__(TPB) fri_final_kernel(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof,
+                                                        uint64_t stride, uint64_t off) {
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= n * batch) return;
+  const uint64_t b = g / n, i = g - b * n;
+  uint32_t w[8];
+  fp_to_wire_words(fp_canon(fp_load(values + g)), w);  // [x.to_bytes() for x in values] (fri.py:214)
+  store8(reinterpret_cast<uint32_t*>(proof + b * stride + off) + 8 * i, w);
+}
+
+}  // namespace
+
+hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(wire_to_limb_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, reinterpret_cast<const uint32_t*>(d_wire),
+                     d_limbs, n);
+  return hipGetLastError();
+}
+hipError_t shk_limb_to_wire(const fp* d_limbs, uint8_t* d_wire, uint64_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(limb_to_wire_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, d_limbs, reinterpret_cast<uint32_t*>(d_wire), n);
+  return hipGetLastError();
+}
+hipError_t shk_fill_seeded(fp* d, uint64_t n, uint64_t seed, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(fill_seeded_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, d, n, seed);
+  return hipGetLastError();
+}
+hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(pointwise_mul_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, a, b, out, n);
+  return hipGetLastError();
+}
+hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, lo, hi, lb, out, n);
+  return hipGetLastError();
+}
+hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st) {
+  const uint64_t total = n * batch;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(pad_copy_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, src, dst, n_in, n, total);
+  return hipGetLastError();
+}
+hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
+                         hipStream_t st) {
+  if (n < 4 || (n & (n - 1)) || batch == 0) return hipErrorInvalidValue;
+  const uint64_t rows = (n >> 2) * batch;
+  if (raw_leaves)
+    hipLaunchKernelGGL(merkle_leaves_kernel<true>, dim3(grid_for(rows)), dim3(TPB), 0, st, d_leaves, n, batch, d_nodes);
+  else
+    hipLaunchKernelGGL(merkle_leaves_kernel<false>, dim3(grid_for(rows)), dim3(TPB), 0, st, d_leaves, n, batch, d_nodes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  uint32_t logn = 0;
+  while ((1ull << logn) < n) ++logn;
+  int L = (int)logn - 2;
+  while (L > 0) {
+    const uint64_t cnt = 1ull << (L - 1);
+    hipLaunchKernelGGL(merkle_upper_kernel, dim3(grid_for(cnt), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    L = L > 9 ? L - 9 : 0;
+  }
+  return hipSuccess;
+}
+hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st) {
+  const uint64_t work = (a.n >> 2) * a.batch;
+  if (!work) return hipSuccess;
+  hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(work)), dim3(TPB), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(fri_sample_kernel, dim3((a.batch + 63) / 64), dim3(64), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  uint32_t l1 = 1, l2;
+  while ((1ull << (l1 - 1)) < a.n) ++l1;  // log2(n) + 1
+  l2 = l1 - 2;                            // log2(n/4) + 1
+  const uint64_t work = ((uint64_t)a.samples * (l2 + 4 * l1) + 1) * a.batch;
+  hipLaunchKernelGGL(fri_gather_kernel, dim3(grid_for(work)), dim3(TPB), 0, st, a, l1, l2);
+  return hipGetLastError();
+}
+hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,
+                         uint64_t off, hipStream_t st) {
+  hipLaunchKernelGGL(fri_final_kernel, dim3(grid_for(n * batch)), dim3(TPB), 0, st, values, n, batch, proof, proof_stride, off);
+  return hipGetLastError();
+}

@@ -1,0 +1,50 @@
+// ntt.hip -- instantiations and launchers of the NTT tile passes (ntt_kernels.cuh).
+#include "ntt_kernels.cuh"
+
+namespace {
+
+template <int LOG_R, bool LAST>
+hipError_t launch(const NttPassArgs& a, hipStream_t st) {
+  constexpr int LOG_T = SHK_TILE_LOG - LOG_R;
+  constexpr int THREADS = 1 << (SHK_TILE_LOG - 2);
+  constexpr size_t LDS = (size_t)32 << SHK_TILE_LOG;
+  auto k = ntt_pass_kernel<LOG_R, LOG_T, LAST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LDS);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const uint64_t tiles = (a.total + ((1ull << LOG_T) - 1)) >> LOG_T;
+  if (tiles == 0) return hipSuccess;
+  if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(THREADS), LDS, st, a);
+  return hipGetLastError();
+}
+
+template <bool LAST>
+hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
+  switch (log_R) {
+    case 2: return launch<2, LAST>(a, st);
+    case 3: return launch<3, LAST>(a, st);
+    case 4: return launch<4, LAST>(a, st);
+    case 5: return launch<5, LAST>(a, st);
+    case 6: return launch<6, LAST>(a, st);
+    case 7: return launch<7, LAST>(a, st);
+    case 8: return launch<8, LAST>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+hipError_t shk_launch_ntt_pass(int log_R, bool last, const NttPassArgs& a, hipStream_t st) {
+  return last ? dispatch<true>(log_R, a, st) : dispatch<false>(log_R, a, st);
+}
+
+hipError_t shk_launch_ntt_tiny(const fp* src, fp* dst, uint32_t n, uint32_t batch, const fp* scale, hipStream_t st) {
+  if (batch == 0) return hipSuccess;
+  hipLaunchKernelGGL(ntt_tiny_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, src, dst, n, batch, scale);
+  return hipGetLastError();
+}

@@ -1,0 +1,210 @@
+// ntt_kernels.cuh -- radix-2^r tile passes of the large NTT over Z/p (replaces the recursive
+// _fft/_simple_ft of starks/fft.py:287-314; same outputs, natural order in and out).
+//
+// Decomposition.  n = R_1 * R_2 * ... * R_m, one kernel launch ("pass") per factor:
+//   pass d < m ("column pass", LAST=false): the array is viewed as [P_d][R_d][S_d] (S_d = n / (P_d R_d));
+//       every column (p, j2) gets an R_d-point NTT along the middle axis, in place, followed by the
+//       inter-pass twiddle  g_d^(j2*k1),  g_d = w^(P_d)  (order R_d*S_d).
+//   pass m ("row pass", LAST=true): contiguous rows of R_m points; the result is scattered to natural
+//       order  out[drev(p) + P*k]  (drev = mixed-radix digit reversal of the row number).
+// A workgroup owns a tile of R x T elements (2048 elements = 64 KiB of LDS -> 2 workgroups per CU):
+// T adjacent columns (T*32 B contiguous per row: coalesced segments) or T rows.  Each thread keeps 4
+// elements in registers and does two butterfly levels (radix-4) between LDS exchanges; the R-point
+// transform is decimation-in-frequency, so the tile's own twiddles come from one table of R/2 powers of
+// w^(n/R) shared by every pass that uses radix R; the bit-reversed order DIF leaves is undone by the
+// store addresses.  The last two levels of each tile transform have twiddles 1 / w^(R/4) only.
+#pragma once
+#include "internal.hpp"
+
+
+// LDS image of a tile: 32-byte elements, 8 to a 256-byte bank row; the slot inside the row is XOR-ed with
+// the higher index bits so that any power-of-two stride between lanes spreads over all 8 slots.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t e) {
+  uint32_t s = (e ^ (e >> 3) ^ (e >> 6) ^ (e >> 9)) & 7u;
+  return (((e >> 3) << 3) | s) * 2u;  // in uint4 units
+}
+__device__ __forceinline__ void lds_put(uint4* lds, uint32_t e, const fp& r) {
+  uint32_t o = lds_slot(e);
+  lds[o] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  lds[o + 1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+__device__ __forceinline__ fp lds_get(const uint4* lds, uint32_t e) {
+  uint32_t o = lds_slot(e);
+  uint4 a = lds[o], b = lds[o + 1];
+  fp r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
+}
+
+__device__ __forceinline__ fp tw_lookup(const NttPassArgs& a, uint64_t e) {
+  if (a.tw_direct) return fp_load(a.tw_lo + e);
+  fp lo = fp_load(a.tw_lo + (e & ((1ull << a.tw_lb) - 1)));
+  fp hi = fp_load(a.tw_hi + (e >> a.tw_lb));
+  return fp_mul(lo, hi);
+}
+
+// Per-thread state carried across the register groups of one tile pass.
+struct TileThread {
+  fp x[4];
+  uint32_t t, ibase;
+  bool active;
+  uint64_t gbase;  // global element offset of (this thread's column/row, i = 0)
+  uint64_t j2;     // column pass: column index inside the prefix block
+  uint64_t obase;  // row pass: output offset of k = 0
+};
+
+// Register group g: fetch 4 elements (global memory for g == 0, LDS otherwise), do its butterfly levels,
+// and hand the elements to the next group through LDS.
+template <int LOG_R, int LOG_T, bool LAST, int g>
+__device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, TileThread& th, uint32_t tid, uint64_t tile0) {
+  constexpr int R = 1 << LOG_R;
+  constexpr int T = 1 << LOG_T;
+  constexpr int G = (LOG_R + 1) / 2;
+  constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;  // position of local bit 0
+  constexpr bool rfast = LAST && g == 0;  // row pass loads: lanes run along the contiguous row
+  uint32_t rest;
+  if (rfast) {
+    rest = tid & (R / 4 - 1);
+    th.t = tid >> (LOG_R - 2);
+  } else {
+    th.t = tid & (T - 1);
+    rest = tid >> LOG_T;
+  }
+  th.ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
+
+  if (g == 0 || (LAST && g == 1)) {
+    // (re)derive the global coordinates of this thread's column/row: t changes between the
+    // rfast mapping of the row pass's first group and the t-fast mapping of the later ones
+    const uint64_t col = tile0 + th.t;
+    th.active = col < a.total;
+    if (LAST) {
+      const uint64_t b = col >> a.log_P;
+      const uint32_t pp = (uint32_t)(col & ((1ull << a.log_P) - 1));
+      // tiles enumerate rows with the FIRST pass's digit fastest, so that a tile's T rows land on
+      // T adjacent output addresses
+      const uint32_t lr1 = a.ndig ? a.dig_log[0] : 0;
+      const uint32_t k1 = pp & ((1u << lr1) - 1u);
+      const uint32_t rst = pp >> lr1;
+      const uint32_t p = (k1 << (a.log_P - lr1)) | rst;
+      uint32_t sh = a.log_P, wl = 0, acc = 0;
+#pragma unroll
+      for (uint32_t d = 0; d < 3; ++d) {
+        if (d < a.ndig) {
+          sh -= a.dig_log[d];
+          acc |= ((p >> sh) & ((1u << a.dig_log[d]) - 1u)) << wl;
+          wl += a.dig_log[d];
+        }
+      }
+      th.gbase = (b << a.log_n) + ((uint64_t)p << LOG_R);
+      th.obase = (b << a.log_n) + acc;
+    } else {
+      th.j2 = col & ((1ull << a.log_S) - 1);
+      th.gbase = ((col >> a.log_S) << (LOG_R + a.log_S)) + th.j2;
+    }
+  }
+
+  // ---- fetch this group's four elements ---------------------------------------------------------
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const uint32_t i = th.ibase | ((uint32_t)h << beta);
+    if (g == 0) {
+      if (th.active) {
+        th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
+      } else {
+        th.x[h] = fp_zero();
+      }
+    } else {
+      th.x[h] = lds_get(lds, (i << LOG_T) | th.t);
+    }
+  }
+
+  // ---- butterfly levels (DIF: a' = a + b, b' = (a - b) * w^((i mod half) * 2^s)) ---------------------
+  constexpr int qhi = LOG_R - 1 - 2 * g;
+#pragma unroll
+  for (int lv = 0; lv < 2; ++lv) {
+    const int q = qhi - lv;  // global bit position of this level; half = 2^q
+    if (q >= 0) {
+      const int lb = q - beta;  // local bit
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int hl = lb == 1 ? pr : 2 * pr;  // lower element of the pair
+        const int hh = hl | (1 << lb);
+        const uint32_t il = th.ibase | ((uint32_t)hl << beta);
+        fp s = fp_add(th.x[hl], th.x[hh]);
+        fp d = fp_sub(th.x[hl], th.x[hh]);
+        if (q == 0) {
+          // twiddle 1
+        } else if (q == 1 && beta == 0) {
+          if (hl & 1) d = fp_mul(d, fp_load(a.wR + (R / 4)));  // w^(R/4), the 4th root of unity
+        } else {
+          const uint32_t ex = (il & ((1u << q) - 1u)) << (LOG_R - 1 - q);
+          d = fp_mul(d, fp_load(a.wR + ex));
+        }
+        th.x[hl] = s;
+        th.x[hh] = d;
+      }
+    }
+  }
+
+  // ---- hand the elements to the next group through LDS ---------------------------------------------
+  if (g < G - 1) {
+    if (g > 0) __syncthreads();  // everyone has finished reading the previous image
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const uint32_t i = th.ibase | ((uint32_t)h << beta);
+      lds_put(lds, (i << LOG_T) | th.t, th.x[h]);
+    }
+    __syncthreads();
+  }
+}
+
+template <int LOG_R, int LOG_T, bool LAST>
+__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2)) ntt_pass_kernel(NttPassArgs a) {
+  static_assert(LOG_R >= 2 && LOG_R <= 8 && LOG_R + LOG_T >= 8, "unsupported tile");
+  constexpr int G = (LOG_R + 1) / 2;  // register groups (two levels each, the last may have one)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t tile0 = (uint64_t)blockIdx.x << LOG_T;
+  TileThread th;
+  th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0;
+  ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
+  if constexpr (G > 1) ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
+  if constexpr (G > 2) ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
+  if constexpr (G > 3) ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0);
+
+  // ---- store: position i of the DIF output holds frequency k = bitrev(i) ----------------------------
+  if (!th.active) return;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const uint32_t i = th.ibase | (uint32_t)h;  // the last group's local bits sit at position 0
+    const uint32_t k = __brev(i) >> (32 - LOG_R);
+    if (LAST) {
+      fp v = th.x[h];
+      if (a.scale) v = fp_mul(v, fp_load(a.scale));
+      fp_store(a.dst + th.obase + ((uint64_t)k << a.log_P), v);
+    } else {
+      fp v = fp_mul(th.x[h], tw_lookup(a, th.j2 * k));
+      fp_store(a.dst + th.gbase + ((uint64_t)k << a.log_S), v);
+    }
+  }
+}
+
+// n <= 2: the reference's naive base case (_simple_ft, fft.py:287-300) is the whole transform.
+static __global__ void ntt_tiny_kernel(const fp* src, fp* dst, uint32_t n, uint32_t batch, const fp* scale) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  if (n == 1) {
+    fp_store(dst + b, fp_load(src + b));
+    return;
+  }
+  fp x0 = fp_load(src + 2ull * b), x1 = fp_load(src + 2ull * b + 1);
+  fp s = fp_add(x0, x1), d = fp_sub(x0, x1);
+  if (scale) {
+    fp sc = fp_load(scale);
+    s = fp_mul(s, sc);
+    d = fp_mul(d, sc);
+  }
+  fp_store(dst + 2ull * b, s);
+  fp_store(dst + 2ull * b + 1, d);
+}

@@ -1,0 +1,77 @@
+"""BLAKE2s Merkle commitment on the MI355X behind the reference's call sites (starks/merkle_tree.py:5-86):
+merkelize(L) -> list[bytes] of length 2n, mk_branch(tree, index), verify_branch(root, index, proof)."""
+import ctypes
+from hashlib import blake2s
+
+from . import _lib
+
+
+def blake(x):
+    return blake2s(x).digest()  # merkle_tree.py:5 (host side: verifier and Fiat-Shamir glue only)
+
+
+def permute4(values):
+    """merkle_tree.py:11-23: out[4i + j] = in[i + j * n/4]"""
+    q = len(values) // 4
+    return [values[i + j * q] for i in range(q) for j in range(4)]
+
+
+def get_index_in_permuted(x, L):
+    """merkle_tree.py:26-33"""
+    q = L // 4
+    return x // q + 4 * (x % q)
+
+
+def _leaf_bytes(L):
+    out = []
+    for x in L:
+        if isinstance(x, bytes):
+            if len(x) != 32:
+                raise NotImplementedError("starks_amd.merkelize hashes 32-byte leaves (field elements) only")
+            out.append(x)
+        elif isinstance(x, int):
+            out.append(x.to_bytes(32, "big"))
+        else:
+            out.append(x.to_bytes())
+    return b"".join(out)
+
+
+def merkelize_bytes(leaves):
+    """leaves: n * 32 bytes in natural order -> 2n * 32 bytes (nodes[0] = zeros, nodes[1] = root)."""
+    n = len(leaves) // 32
+    if n < 4 or n & (n - 1):
+        raise NotImplementedError("starks_amd.merkelize needs a power-of-two number of leaves >= 4 (got %d)" % n)
+    out = ctypes.create_string_buffer(64 * n)
+    _lib.check(_lib.lib().sh_merkelize(_lib.ctx(), leaves, n, out), "sh_merkelize")
+    return out.raw
+
+
+def merkelize(L):
+    """merkle_tree.py:36-56.  Leaves may be ints, 32-byte strings or field elements (:47-53)."""
+    raw = merkelize_bytes(_leaf_bytes(list(L)))
+    nodes = [raw[i:i + 32] for i in range(0, len(raw), 32)]
+    nodes[0] = b""  # the reference leaves b'' in slot 0
+    return nodes
+
+
+def mk_branch(tree, index):
+    """merkle_tree.py:59-68: the leaf, then one sibling per level (root excluded)."""
+    half = len(tree) // 2
+    index = get_index_in_permuted(index, half) + half
+    o = [tree[index]]
+    while index > 1:
+        o.append(tree[index ^ 1])
+        index //= 2
+    return o
+
+
+def verify_branch(root, index, proof, output_as_int=False):
+    """merkle_tree.py:71-86"""
+    half = 2**len(proof) // 2
+    index = get_index_in_permuted(index, half) + half
+    v = proof[0]
+    for p in proof[1:]:
+        v = blake(p + v) if index % 2 else blake(v + p)
+        index //= 2
+    assert v == root
+    return int.from_bytes(proof[0], "big") if output_as_int else proof[0]

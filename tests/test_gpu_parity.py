@@ -1,0 +1,329 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): every call goes through the C ABI of
+libstarkhip.so (via the ctypes mirror in starks_amd/) and is compared bit-for-bit with the CPU oracle on
+the same inputs and with the fixtures generated from the live reference (tests/golden)."""
+import hashlib
+import os
+import random
+import struct
+
+import pytest
+
+from conftest import load_golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+P = 2**256 - 2**32 * 351 + 1
+
+
+def h2i(s):
+    return int(s, 16)
+
+
+def wire(vals):
+    return b"".join(int(v).to_bytes(32, "big") for v in vals)
+
+
+def unwire(b):
+    return [int.from_bytes(b[i:i + 32], "big") for i in range(0, len(b), 32)]
+
+
+def seeded(seed, i):
+    return int.from_bytes(hashlib.blake2s(struct.pack("<QQ", seed, i)).digest(), "big") % P
+
+
+def root_of(n):
+    return pow(7, (P - 1) // n, P)
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import starks_amd
+    from starks_amd import _lib, fft, merkle_tree, utils, fri, compression
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.pkg, ns.lib, ns.fft, ns.mt, ns.utils, ns.fri, ns.comp = starks_amd, _lib, fft, merkle_tree, utils, fri, compression
+    ns.F = starks_amd.IntegersModP(P)
+    _lib.ctx()  # fails loudly when the extension or the GPU is missing
+    return ns
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import coracle, pyoracle
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.c, ns.py = coracle, pyoracle
+    return ns
+
+
+# ---- NTT ---------------------------------------------------------------------------------------------
+def test_ntt_golden_vectors(sa):
+    g = load_golden("ntt.json")
+    for c in g["cases"]:
+        n, n_in, w = c["n"], c["n_in"], h2i(c["w"])
+        data = wire(seeded(g["seed"], i) for i in range(n_in))
+        fwd = sa.fft.ntt_bytes(data, n, w)
+        inv = sa.fft.ntt_bytes(data, n, w, inverse=True)
+        assert hashlib.sha256(fwd).hexdigest() == c["sha_fwd"], "fwd n=%d" % n
+        assert hashlib.sha256(inv).hexdigest() == c["sha_inv"], "inv n=%d" % n
+        if "fwd" in c:
+            assert unwire(fwd) == [h2i(v) for v in c["fwd"]]
+        # x == invNTT(NTT(x)), zero-padded (test_fft.py:132-149 round trip)
+        assert sa.fft.ntt_bytes(fwd, n, w, inverse=True) == data + bytes(32 * (n - n_in))
+
+
+@pytest.mark.parametrize("logn", list(range(0, 21)))
+def test_ntt_every_size_vs_oracle(sa, oracle, logn):
+    """All plan shapes (tiny, one, two and three passes; odd and even radices) against the C oracle."""
+    n = 1 << logn
+    w = root_of(n)
+    rng = random.Random(logn)
+    if logn <= 16:
+        vals = [rng.randrange(2**256) for _ in range(n)]  # unreduced inputs allowed (modp.py:33-34)
+        vals[0] = 2**256 - 1
+        if n > 1:
+            vals[-1] = P
+        data = wire(vals)
+        exp_f = oracle.c.fft_bytes(data, n, w)
+        exp_i = oracle.c.fft_bytes(data, n, w, inverse=True)
+        assert sa.fft.ntt_bytes(data, n, w) == exp_f
+        assert sa.fft.ntt_bytes(data, n, w, inverse=True) == exp_i
+    else:
+        # too slow for the scalar oracle in a unit test: round trip + linearity + Parseval-like point checks
+        data = bytes(rng.getrandbits(8) for _ in range(32 * 8)) * (n // 8)
+        fwd = sa.fft.ntt_bytes(data, n, w)
+        assert sa.fft.ntt_bytes(fwd, n, w, inverse=True) == wire(v % P for v in unwire(data))
+        xs = unwire(data)
+        for k in (0, 1, n // 2, n - 1):  # out[k] = sum_j x_j w^(jk): check k=0 and k=n/2 exactly
+            if k == 0:
+                assert int.from_bytes(fwd[:32], "big") == sum(xs) % P
+            if k == n // 2:
+                assert int.from_bytes(fwd[32 * k:32 * k + 32], "big") == (sum(xs[0::2]) - sum(xs[1::2])) % P
+
+
+def test_ntt_padding_and_batch(sa, oracle):
+    n, w = 4096, root_of(4096)
+    rng = random.Random(5)
+    rows = [[rng.randrange(P) for _ in range(1000)] for _ in range(3)]
+    got = sa.fft.ntt_bytes(b"".join(wire(r) for r in rows), n, w, batch=3)
+    for b, r in enumerate(rows):
+        assert got[b * 32 * n:(b + 1) * 32 * n] == oracle.c.fft_bytes(wire(r), n, w)
+    # empty input -> all zeros; n_in > n -> error
+    assert sa.fft.ntt_bytes(b"", 16, root_of(16)) == bytes(32 * 16)
+    with pytest.raises(ValueError):
+        sa.fft.ntt_bytes(bytes(32 * 32), 16, root_of(16))
+    # root of the wrong order is refused (fft.py:319-321 would walk a different cycle)
+    rc = sa.lib.lib().sh_ntt(sa.lib.ctx(), bytes(64), 2, __import__("ctypes").create_string_buffer(32 * 8), 8,
+                            root_of(16).to_bytes(32, "big"), 0)
+    assert rc == -2
+
+
+def test_reference_call_sites_fft(sa):
+    """The reference's own tests, through the drop-in API (test_fft.py:115-130, 185-194; Appendix A)."""
+    F = sa.F
+    from starks_amd.polynomial import polynomials_over
+    polys = polynomials_over(F).factory
+    g = load_golden("ntt.json")
+    w8 = F(7) ** ((P - 1) // 8)
+    ev = sa.fft.NonBinaryFFT(F, w8).fft(polys([0, 1, 2, 3]))
+    assert len(ev) == 8 and all(isinstance(v, F) for v in ev)
+    assert [int(v) for v in ev] == [h2i(v) for v in g["mimc_n8_0123"]["fwd"]]
+    assert ev[4] == P - 2  # P(-1) = -2
+    back = sa.fft.NonBinaryFFT(F, w8).inv_fft(ev)
+    assert back == polys([0, 1, 2, 3]) and len(back.coefficients) == 4  # trailing zeros stripped
+    m = g["inv_fft_strip"]
+    assert [int(c) for c in sa.fft.NonBinaryFFT(F, F(7) ** ((P - 1) // 16)).inv_fft([h2i(v) for v in m["values"]]).coefficients] == [5, 6, 7]
+    prod = sa.fft.mul_polys([F(v) for v in range(4)], [F(v) for v in range(4)], F(7) ** ((P - 1) // 512))
+    assert [int(v) for v in prod[:16]] == g["mul_polys_0123"]["first16"]
+    assert hashlib.sha256(wire(prod)).hexdigest() == g["mul_polys_0123"]["sha"]
+    with pytest.raises(NotImplementedError):  # mod-31 fields are outside the accelerated path
+        F31 = sa.pkg.IntegersModP(31)
+        sa.fft.fft_1d(F31, [0, 1, 2, 3], 31, F31(26))
+
+
+def test_power_cycle(sa):
+    g = load_golden("utils.json")
+    F = sa.F
+    assert [v.to_bytes().hex() for v in sa.utils.get_power_cycle(F(root_of(8)), F)] == g["power_cycle_w8"]
+    assert hashlib.sha256(wire(sa.utils.get_power_cycle(F(root_of(64)), F))).hexdigest() == g["power_cycle_w64_sha"]
+    n = 1 << 18
+    cyc = sa.utils.get_power_cycle(F(root_of(n)), F)
+    assert len(cyc) == n and cyc[1] == root_of(n) and int(cyc[-1]) * root_of(n) % P == 1
+    assert int(cyc[12345]) == pow(root_of(n), 12345, P)
+
+
+# ---- Merkle -------------------------------------------------------------------------------------------
+def test_merkle_golden(sa):
+    g = load_golden("merkle.json")
+    t = sa.mt.merkelize([x.to_bytes(32, "big") for x in range(128)])
+    assert t[1].hex() == g["range128"]["root"] and len(t) == 256 and t[0] == b""
+    assert hashlib.sha256(b"".join(t)).hexdigest() == g["range128"]["tree_sha"]
+    b = sa.mt.mk_branch(t, 59)
+    assert [x.hex() for x in b] == g["range128"]["branch59"] and len(b) == 8
+    assert sa.mt.verify_branch(t[1], 59, b, output_as_int=True) == 59  # test_merkle_tree.py:16-22
+    t = sa.mt.merkelize([x.to_bytes(32, "big") for x in range(256)])
+    assert t[1].hex() == g["range256"]["root"] and len(sa.mt.mk_branch(t, 59)) == 9
+    t = sa.mt.merkelize([sa.F(1), sa.F(2), sa.F(3), sa.F(4)])
+    assert [x.hex() for x in t] == g["f1234"]["tree"]
+    assert sa.mt.merkelize([5, 6, 7, 8])[1].hex() == g["mixed5678_root"]
+    for c in g["seeded"]:
+        vals = [seeded(c["seed"], i) for i in range(c["n"])]
+        t = sa.mt.merkelize(vals)
+        assert t[1].hex() == c["root"]
+        assert hashlib.sha256(b"".join(t)).hexdigest() == c["tree_sha"]
+        for i, br in c["branches"].items():
+            assert [x.hex() for x in sa.mt.mk_branch(t, int(i))] == br
+
+
+@pytest.mark.parametrize("logn", [2, 3, 5, 9, 10, 11, 12, 13, 17, 20])
+def test_merkle_sizes_vs_oracle(sa, oracle, logn):
+    n = 1 << logn
+    rng = random.Random(logn)
+    leaves = bytes(rng.getrandbits(8) for _ in range(32 * min(n, 4096))) * max(1, n // 4096)
+    assert sa.mt.merkelize_bytes(leaves) == oracle.c.merkelize_bytes(leaves)
+
+
+# ---- FRI ----------------------------------------------------------------------------------------------
+def test_fold_golden(sa, oracle):
+    import ctypes
+    for c in load_golden("fold.json"):
+        n = c["n"]
+        values = wire(seeded(c["seed"], i) for i in range(n))
+        out = ctypes.create_string_buffer(8 * n)
+        rc = sa.lib.lib().sh_fri_fold(sa.lib.ctx(), values, n, h2i(c["w"]).to_bytes(32, "big"),
+                                     bytes.fromhex(c["special_x_bytes"]), out)
+        assert rc == 0
+        assert hashlib.sha256(out.raw).hexdigest() == c["column_sha"]
+    # bigger, against the C oracle's Lagrange-interpolation fold
+    n = 1 << 14
+    vals = [seeded(3, i) for i in range(n)]
+    sx = hashlib.blake2s(b"q").digest()
+    out = ctypes.create_string_buffer(8 * n)
+    assert sa.lib.lib().sh_fri_fold(sa.lib.ctx(), wire(vals), n, root_of(n).to_bytes(32, "big"), sx, out) == 0
+    assert unwire(out.raw) == oracle.c.fold(vals, root_of(n), sx)
+
+
+def _fri_coeffs(rec, oracle):
+    d = rec["coeffs"]
+    if d.startswith("(i**7)^42"):
+        return [(i**7) ^ 42 for i in range(rec["n_coeffs"])]
+    if d == "i, i<256":
+        return list(range(256))
+    if d == "i+1, i<16":
+        return list(range(1, 17))
+    k = int(d.split("2^")[1].rstrip("))"))
+    coeffs = oracle.c.fft(oracle.py.mimc_trace(3, 2**k), 2**k, pow(h2i(rec["w"]), 8, P), inverse=True)
+    return oracle.py.strip_trailing_zeros(coeffs)
+
+
+@pytest.mark.parametrize("rec", load_golden("fri.json"), ids=lambda r: r["name"])
+def test_fri_proofs_golden(sa, oracle, rec):
+    """Proof bytes == the reference's, for every fixture incl. config C3 (2^14-step MiMC trace, N = 2^17)."""
+    coeffs = _fri_coeffs(rec, oracle)
+    w = h2i(rec["w"])
+    n = sa.lib.order_of_root(w)
+    flat = sa.fri.prove_flat(wire(coeffs), n, w, rec["maxdeg_plus_1"], rec["exclude_multiples_of"], rec["samples"])
+    assert len(flat) == rec["flat_len"]
+    assert hashlib.sha256(flat).hexdigest() == rec["flat_sha"]
+    proof = sa.fri.prove_low_degree(coeffs, sa.F(w), rec["maxdeg_plus_1"], rec["exclude_multiples_of"], rec["samples"])
+    assert len(proof) == rec["len_proof"]
+    assert [r[0].hex() for r in proof[:-1]] == [r["root_m2"] for r in rec["rounds"]]
+    assert [x.hex() for x in proof[-1]] == rec["final_values"]
+    assert [[len(b) for b in proof[r][1][0]] for r in range(len(proof) - 1)] == rec["branch_lens"]
+    pb = sa.comp.proof_bytes(sa.comp.compress_fri(proof))  # the reference's "proof bytes" (compression.py)
+    assert (len(pb), hashlib.sha256(pb).hexdigest()) == (rec["proof_bytes_len"], rec["proof_bytes_sha"])
+    path = os.path.join(GOLDEN, rec["name"] + ".proof.bin")
+    if os.path.exists(path):
+        assert open(path, "rb").read() == pb
+    if rec["samples"] == 40:  # prove -> verify round trip (test_fri.py:136-182)
+        assert sa.fri.SmoothSubgroupFRI(sa.F).verify_proximity_proof(
+            proof, bytes.fromhex(rec["eval_root"]), sa.F(w), rec["maxdeg_plus_1"], rec["exclude_multiples_of"])
+
+
+def test_fri_reference_test_shapes(sa):
+    """test_fri.py:105-134 (commented in the reference): 4 proof items, 40 branch sets, 8 final values."""
+    F = sa.F
+    from starks_amd.polynomial import polynomials_over
+    poly = polynomials_over(F).factory([F((i**7) ^ 42) for i in range(512)])
+    proof = sa.fri.SmoothSubgroupFRI(F).generate_proximity_proof(poly, F(7) ** ((P - 1) // 512), 512)
+    assert len(proof) == 4
+    for i, rp in enumerate(proof):
+        if i < 3:
+            assert len(rp) == 2 and len(rp[1]) == 40
+        else:
+            assert len(rp) == 8
+
+
+def test_fri_batch_and_oracle(sa, oracle):
+    """Batched proofs of independent traces (config C5 in miniature) == one-at-a-time C oracle proofs."""
+    steps, ext = 256, 8
+    n = steps * ext
+    g2 = root_of(n)
+    coeffs = []
+    for j in range(5):
+        c = oracle.c.fft(oracle.py.mimc_trace(3 + j, steps), steps, pow(g2, ext, P), inverse=True)
+        coeffs.append(wire(c))
+    flat = sa.fri.prove_flat(b"".join(coeffs), n, g2, steps, ext, 40, batch=5)
+    plen = sa.fri.proof_len(n, steps, 40)
+    for j in range(5):
+        assert flat[j * plen:(j + 1) * plen] == oracle.c.fri_prove_flat(coeffs[j], g2, steps, ext, 40)
+
+
+def test_fri_invalid_arguments(sa):
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    out = ctypes.create_string_buffer(1 << 20)
+    w = root_of(64).to_bytes(32, "big")
+    assert L.sh_fri_prove(ctx, bytes(32 * 65), 65, 64, w, 64, 0, 40, 1, out, 1 << 20) == -1  # n_coeffs > n
+    assert L.sh_fri_prove(ctx, bytes(32 * 64), 64, 64, w, 64, 0, 40, 1, out, 16) == -5        # buffer too small
+    assert L.sh_fri_prove(ctx, bytes(32 * 64), 64, 64, root_of(128).to_bytes(32, "big"), 64, 0, 40, 1, out, 1 << 20) == -2
+
+
+# ---- LDE ----------------------------------------------------------------------------------------------
+def test_lde_golden(sa, oracle):
+    for c in load_golden("lde.json"):
+        tr = oracle.py.mimc_trace(c["trace_t0"], c["steps"])
+        ext = sa.fft.low_degree_extension(sa.F, [tr], c["ext"], sa.F(h2i(c["g2"])))[0]
+        assert hashlib.sha256(wire(ext)).hexdigest() == c["lde_sha"]
+        assert [int(v) for v in ext[::8]] == tr
+    # several columns at once
+    steps = 512
+    g2 = root_of(steps * 8)
+    cols = [oracle.py.mimc_trace(3 + j, steps) for j in range(3)]
+    got = sa.fft.low_degree_extension(sa.F, cols, 8, sa.F(g2))
+    for j in range(3):
+        assert wire(got[j]) == oracle.c.lde_bytes(wire(cols[j]), 8, g2)
+
+
+# ---- device-resident API (what bench.py times) --------------------------------------------------------------
+def test_device_resident_pipeline(sa, oracle):
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << 12
+    w = root_of(n)
+    d_x, d_y, d_t = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(d_x)) == 0
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(d_y)) == 0
+    assert L.sh_dev_alloc(ctx, 64 * n, ctypes.byref(d_t)) == 0
+    assert L.sh_dev_fill_seeded(ctx, d_x, n, 0x5eed) == 0
+    host = ctypes.create_string_buffer(32 * n)
+    assert L.sh_dev_to_wire(ctx, d_x, host, n) == 0
+    assert host.raw == wire(seeded(0x5eed, i) for i in range(n))  # same generator as the fixtures
+    assert L.sh_dev_ntt(ctx, d_x, d_y, n, 1, w.to_bytes(32, "big"), 0) == 0
+    assert L.sh_dev_to_wire(ctx, d_y, host, n) == 0
+    assert hashlib.sha256(host.raw).hexdigest() == [c for c in load_golden("ntt.json")["cases"] if c["n"] == n][0]["sha_fwd"]
+    assert L.sh_dev_merkelize(ctx, d_y, n, 1, d_t) == 0
+    tree = ctypes.create_string_buffer(64 * n)
+    assert L.sh_dev_download(ctx, d_t, tree, 64 * n) == 0
+    assert tree.raw == oracle.c.merkelize_bytes(host.raw)
+    assert L.sh_dev_ntt(ctx, d_y, d_y, n, 1, w.to_bytes(32, "big"), 1) == 0  # in place inverse
+    assert L.sh_dev_to_wire(ctx, d_y, host, n) == 0
+    assert host.raw == wire(seeded(0x5eed, i) for i in range(n))
+    for d in (d_x, d_y, d_t):
+        assert L.sh_dev_free(ctx, d) == 0

@@ -1,0 +1,92 @@
+"""CPU-only checks of the host logic: the C-ABI library loads and exports every symbol the header
+declares (no compute without a GPU), the boundary element type, proof (un)packing and compression."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_golden
+
+P = 2**256 - 2**32 * 351 + 1
+
+
+def _build():
+    import __graft_entry__ as ge
+    ge.build()
+
+
+def test_library_exports_every_declared_symbol():
+    _build()
+    from starks_amd import _lib
+    header = open(os.path.join(ROOT, "include", "starkhip.h")).read()
+    declared = sorted(set(re.findall(r"\b(sh_[a-z_0-9]+)\s*\(", header)))
+    assert declared == _lib.exported_symbols()  # lib() getattr()s each one: a missing export raises
+    assert _lib.lib().sh_version().startswith(b"starkhip")
+    assert _lib.lib().sh_strerror(-2) == b"root_of_unity does not have order n"
+    assert _lib.lib().sh_fri_proof_len(512, 512, 40) == load_golden("fri.json")[0]["flat_len"]
+
+
+def test_no_cpu_fallback_without_gpu():
+    _build()
+    from starks_amd import _lib, fft, IntegersModP
+    if _lib.lib().sh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    F = IntegersModP(P)
+    with pytest.raises(_lib.StarkHipError):
+        fft.fft_1d(F, [1, 2, 3], P, F(7) ** ((P - 1) // 8))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "starks_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "liboracle" not in src and "pyoracle" not in src.replace("see pyoracle", ""), f
+
+
+def test_field_element_semantics():
+    """modp.py call surface incl. the reference's KATs (test_modpy.py:28-35,54-61)."""
+    from starks_amd import IntegersModP
+    F = IntegersModP(P)
+    assert F is IntegersModP(P)
+    assert F(2**256) == F(2**32 * 351 - 1) and F(5) != F(11)
+    assert int(F(7) ** ((P - 1) // 512)) == pow(7, (P - 1) // 512, P)
+    assert F(b"\xff" * 32).n == 2**256 - 1  # bytes ctor does not reduce
+    assert (F(b"\xff" * 32) * 1).n == (2**256 - 1) % P
+    assert F(3) * 5 == 15 and 5 * F(3) == 15 and 1 - F(2) == P - 1 and -F(1) == P - 1
+    assert F(3) / F(3) == 1 and 1 / F(2) * 2 == 1 and F(5).inverse() * 5 == 1
+    assert F(5).to_bytes() == (5).to_bytes(32, "big")
+    m7 = IntegersModP(7)
+    assert m7(5) == 1 / m7(3) and m7(0) == m7(3) + m7(4)
+    g = load_golden("field.json")
+    for c in g["cases"][:50]:
+        a, b = F(int(c["a"], 16)), F(int(c["b"], 16))
+        assert (a + b).to_bytes().hex() == c["add"] and (a - b).to_bytes().hex() == c["sub"] and (a * b).to_bytes().hex() == c["mul"]
+
+
+def test_unpack_and_compress_against_golden():
+    from starks_amd import fri, compression
+    rec = [r for r in load_golden("fri.json") if r["name"] == "fri_deg512"][0]
+    flat = open(os.path.join(ROOT, "tests", "golden", "fri_deg512.flat.bin"), "rb").read()
+    proof = fri.unpack_proof(flat, 512, 512, 40)
+    assert len(proof) == 4 and [len(b) for b in proof[0][1][0]] == rec["branch_lens"][0]
+    c = compression.compress_fri(proof)
+    assert compression.decompress_fri(c) == proof
+    assert compression.proof_bytes(c) == open(os.path.join(ROOT, "tests", "golden", "fri_deg512.proof.bin"), "rb").read()
+    assert compression.bin_length(c) == rec["proof_bytes_len"]
+    g = load_golden("compression.json")
+    br = [[bytes.fromhex(x) for x in b] for b in g["branches"]]
+    assert [x.hex() for x in compression.compress_branches(br)] == g["compressed"]
+    # host verifier accepts the reference-generated proof and rejects a corrupted one
+    assert fri.verify_low_degree_proof(proof, bytes.fromhex(rec["eval_root"]), int(rec["w"], 16), 512)
+    bad = [[proof[0][0], [[list(b) for b in bs] for bs in proof[0][1]]]] + proof[1:]
+    bad[0][1][3][0][0] = b"\x01" * 32
+    with pytest.raises(AssertionError):
+        fri.verify_low_degree_proof(bad, bytes.fromhex(rec["eval_root"]), int(rec["w"], 16), 512)
+
+
+def test_host_index_sampling_matches_golden():
+    from starks_amd.utils import get_pseudorandom_indices
+    for c in load_golden("utils.json")["pseudorandom_indices"]:
+        assert get_pseudorandom_indices(bytes.fromhex(c["entropy"]), c["modulus"], c["count"], c["exclude"]) == c["out"]
