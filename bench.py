@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot-path benchmark (driver contract: one JSON line on rank 0).
+
+Metric (BASELINE.json): NTT field elements per second.  Workload at every N: BASELINE configs[1] -- a
+2^20-point forward NTT followed by the inverse NTT over the MiMC prime, data resident in HBM, one
+independent vector per GPU (weak scaling, no data-path collective: SURVEY 8(e)).  A "step" = one forward +
+one inverse transform = 2 * 2^20 transformed elements.  `value` = elements of all ranks / max-over-ranks time.
+
+Also on the same line:
+  roofline      -- the NTT tile-pass kernel (the dominant kernel): algorithmic bytes (64 B per element per
+                   transform) / HIP-event time of the timed region on the library's stream.
+  cpu_baseline  -- the C oracle (oracle/oracle.c: the reference's recursive algorithm, one core) on a
+                   bounded sample of the same workload, rank 0 at N=1 only.
+  extra         -- 2^24-point NTT (config 4), FRI commit of a 2^14-step (config 3) and a 2^20-step MiMC trace,
+                   Merkle commit of 2^24 leaves: ms, elements/s, field-mul-equivalents/s, algorithmic GB/s.
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P = 2**256 - 2**32 * 351 + 1
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def root_of(n):
+    return pow(7, (P - 1) // n, P)
+
+
+class Dev:
+    """Thin helper over the device-resident C ABI."""
+
+    def __init__(self):
+        from starks_amd import _lib
+        self.L = _lib.lib()
+        self.ctx = _lib.ctx()
+        self._lib = _lib
+
+    def ck(self, rc, what):
+        self._lib.check(rc, what)
+
+    def alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self.ck(self.L.sh_dev_alloc(self.ctx, nbytes, ctypes.byref(p)), "sh_dev_alloc")
+        return p
+
+    def free(self, p):
+        self.ck(self.L.sh_dev_free(self.ctx, p), "sh_dev_free")
+
+    def sync(self):
+        self.ck(self.L.sh_sync(self.ctx), "sh_sync")
+
+    def timed(self, fn, reps):
+        """HIP-event time (ms per rep) of `reps` calls of fn on the library stream."""
+        fn()
+        self.sync()
+        self.ck(self.L.sh_timer_start(self.ctx), "timer")
+        for _ in range(reps):
+            fn()
+        ms = ctypes.c_float()
+        self.ck(self.L.sh_timer_stop(self.ctx, ctypes.byref(ms)), "timer")
+        return ms.value / reps
+
+
+def extras(dev, quick):
+    """Secondary legs, rank 0 at N=1 only (not part of `value`)."""
+    L, ctx = dev.L, dev.ctx
+    out = {}
+    # ---- config 4: 2^24-point NTT ------------------------------------------------------------------
+    for logn in ([22] if quick else [24]):
+        n = 1 << logn
+        w = root_of(n).to_bytes(32, "big")
+        dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
+        dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed), "fill")
+        ms = dev.timed(lambda: dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"), 10)
+        # size-independent check: inverse brings the input back (digest of both)
+        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")
+        chk = 1 << 16
+        a, b = ctypes.create_string_buffer(32 * chk), ctypes.create_string_buffer(32 * chk)
+        dev.ck(L.sh_dev_to_wire(ctx, dx, a, chk), "dl")
+        dev.ck(L.sh_dev_to_wire(ctx, dy, b, chk), "dl")
+        out["ntt_2^%d" % logn] = {
+            "ms": round(ms, 4), "elements_per_s": n / ms * 1e3,
+            "field_mul_eq_per_s": (n // 2) * logn / ms * 1e3,
+            "algorithmic_GBps": 64.0 * n / ms / 1e6, "hbm_frac": 64.0 * n / ms / 1e6 / HBM_PEAK_GBS,
+            "roundtrip_ok": a.raw == b.raw}
+        dev.free(dx)
+        dev.free(dy)
+    # ---- Merkle commit -----------------------------------------------------------------------------
+    logn = 20 if quick else 24
+    n = 1 << logn
+    dx, dt = dev.alloc(32 * n), dev.alloc(64 * n)
+    dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 7), "fill")
+    ms = dev.timed(lambda: dev.ck(L.sh_dev_merkelize(ctx, dx, n, 1, dt), "merkle"), 10)
+    out["merkelize_2^%d" % logn] = {"ms": round(ms, 4), "leaves_per_s": n / ms * 1e3,
+                                    "algorithmic_GBps": 64.0 * n / ms / 1e6}
+    dev.free(dx)
+    dev.free(dt)
+    # ---- FRI commit: 2^14-step (config 3) and 2^20-step MiMC trace, 8x extension ---------------------
+    for logsteps in ([14] if quick else [14, 16, 20]):
+        steps, ext = 1 << logsteps, 8
+        n = steps * ext
+        g2 = root_of(n)
+        w = g2.to_bytes(32, "big")
+        plen = int(L.sh_fri_proof_len(n, steps, 40))
+        dc, dp = dev.alloc(32 * n), dev.alloc(plen)
+        # synthetic coefficients: the degree < steps polynomial with seeded coefficients (same cost as a trace poly)
+        dev.ck(L.sh_dev_fill_seeded(ctx, dc, n, 0xF51), "fill")
+        # zero the upper 7/8 so that deg < steps
+        z = bytes(32 * (n - steps))
+        dev.ck(L.sh_dev_upload(ctx, z, ctypes.c_void_p(dc.value + 32 * steps), len(z)), "upload")
+        ms = dev.timed(lambda: dev.ck(L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, 1, dp), "fri"), 5)
+        out["fri_commit_steps_2^%d" % logsteps] = {"ms": round(ms, 4), "domain": n, "proof_bytes": plen,
+                                                   "algorithmic_GBps": 203.0 * n / ms / 1e6}
+        dev.free(dc)
+        dev.free(dp)
+    return out
+
+
+def cpu_baseline(logn, budget_s=20.0):
+    """The C oracle (reference algorithm, scalar, 1 core) on the same forward+inverse workload."""
+    from oracle import coracle
+    import struct
+    n = 1 << logn
+    data = b"".join(hashlib.blake2s(struct.pack("<QQ", 0x5eed, i)).digest() for i in range(n))
+    w = root_of(n)
+    t0 = time.time()
+    steps = 0
+    while True:
+        f = coracle.fft_bytes(data, n, w)
+        coracle.fft_bytes(f, n, w, inverse=True)
+        steps += 1
+        if time.time() - t0 > budget_s / 2 or steps >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": 2 * n * steps / dt, "unit": "elements/s", "cores": 1, "kind": "port",
+            "sample": "%d step(s) of the same 2^%d forward+inverse NTT with oracle/oracle.c (%.1f s)" % (steps, logn, dt),
+            "digest": hashlib.sha256(f).hexdigest()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--logn", type=int, default=20, help="log2 transform length (configs[1] = 20)")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="smaller secondary legs")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("STARKHIP_DEVICE", str(local_rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    dev = Dev()
+    L, ctx = dev.L, dev.ctx
+    n = 1 << args.logn
+    w = root_of(n).to_bytes(32, "big")
+    dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
+    dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed + rank), "fill")  # an independent vector per rank
+
+    def step():
+        dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt")   # y = NTT(x)
+        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")  # y = invNTT(y) == x
+
+    def fence():
+        dev.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    dev.ck(L.sh_timer_start(ctx), "timer")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ev_ms = ctypes.c_float()
+    dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev_ms)), "timer")  # HIP events on the library's stream
+    fence()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    # correctness of what was timed: x == invNTT(NTT(x)) and the forward digest against the fixture (rank 0)
+    a, b = ctypes.create_string_buffer(32 * n), ctypes.create_string_buffer(32 * n)
+    dev.ck(L.sh_dev_to_wire(ctx, dx, a, n), "dl")
+    dev.ck(L.sh_dev_to_wire(ctx, dy, b, n), "dl")
+    roundtrip_ok = a.raw == b.raw
+    dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt")
+    dev.ck(L.sh_dev_to_wire(ctx, dy, b, n), "dl")
+    fwd_digest = hashlib.sha256(b.raw).hexdigest()
+    golden_ok = None
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ntt.json")))
+        hit = [c for c in gold["cases"] if c["n"] == n and c["n_in"] == n]
+        if hit and rank == 0:
+            golden_ok = hit[0]["sha_fwd"] == fwd_digest
+    except Exception:
+        pass
+    ok = torch.tensor([1 if roundtrip_ok and golden_ok is not False else 0], device="cuda")
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the only exchange: a 1-word status gather over RCCL
+
+    elems_per_step = 2 * n
+    value = elems_per_step * args.steps * world / dt_max
+    alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
+    achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
+    line = {
+        "metric": "ntt_field_elements_per_sec", "value": value, "unit": "elements/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU)",
+        "data": "synthetic", "config": {
+            "workload": "configs[1]: 2^%d-point NTT + inverse NTT over the MiMC prime, one vector per GPU, "
+                        "x == invNTT(NTT(x)) checked" % args.logn,
+            "n": n, "elements_per_step": elems_per_step, "parallelism": "independent vectors x%d" % world},
+        "field_mul_eq_per_s": (n // 2) * args.logn * 2 * args.steps * world / dt_max,
+        "check": {"roundtrip_ok": bool(int(ok.item())), "fwd_sha256": fwd_digest, "matches_reference_fixture": golden_ok},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "ntt_pass_kernel (3 launches per 2^20 transform)",
+                     "note": "integer-ALU bound: ~13 256-bit modmuls per element per transform; see DESIGN.md section 6"},
+    }
+    if rank == 0 and world == 1:
+        line["cpu_baseline"] = cpu_baseline(args.logn)
+        line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
+        if not args.no_extras:
+            line["extra"] = extras(dev, args.quick)
+    dev.free(dx)
+    dev.free(dy)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
