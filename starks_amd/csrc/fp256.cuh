@@ -191,10 +191,18 @@ FP_HD fp fp_reduce_wide(const uint32_t t[16]) {
   return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fp256_mulasm.inc"  // fp_mul_wide_asm: the same product as fp_mul_wide, hand-scheduled for gfx950
+#endif
+
 // (a * b) mod p, lazily reduced.  modp.py:51-53.
 FP_HD fp fp_mul(const fp& a, const fp& b) {
   uint32_t t[16];
+#if defined(__HIP_DEVICE_COMPILE__)
+  fp_mul_wide_asm(a.v, b.v, t);
+#else
   fp_mul_wide(a.v, b.v, t);
+#endif
   return fp_reduce_wide(t);
 }
 
