@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--logn", type=int, default=20, help="log2 transform length (configs[1] = 20)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--quick", action="store_true", help="smaller secondary legs")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -240,8 +241,9 @@ def main():
                      "note": "integer-ALU bound: ~13 256-bit modmuls per element per transform; see DESIGN.md section 6"},
     }
     if rank == 0 and world == 1:
-        line["cpu_baseline"] = cpu_baseline(args.logn)
-        line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.logn)
+            line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
         if not args.no_extras:
             line["extra"] = extras(dev, args.quick)
     dev.free(dx)

@@ -1,0 +1,55 @@
+"""The N > 1 path on CPU: two processes, gloo backend.  The GPU work is replaced by a deterministic stand-in
+(the sharding, rendezvous, max-over-ranks timing and the digest all_gather are what is under test)."""
+import hashlib
+import os
+import subprocess
+import sys
+import textwrap
+
+from conftest import ROOT
+
+
+def test_shard_partitions():
+    from starks_amd.batch import shard
+    for total in (0, 1, 7, 8, 512, 513):
+        for world in (1, 2, 3, 8):
+            parts = [list(shard(total, r, world)) for r in range(world)]
+            assert sum(parts, []) == list(range(total))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import hashlib, os, sys, time
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from starks_amd.batch import shard, gather_digests
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    total = 11
+    mine = shard(total, rank, world)
+    t0 = time.perf_counter()
+    local = [hashlib.sha256(b"proof-%%d" %% j).digest() for j in mine]   # stand-in for the per-unit GPU proof
+    dt = torch.tensor([time.perf_counter() - t0 + 0.01 * rank], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)                            # bench.py's max-over-ranks time
+    allp = gather_digests(local, total, rank, world, dist, "cpu")
+    want = [hashlib.sha256(b"proof-%%d" %% j).digest() for j in range(total)]
+    assert allp == want, (rank, len(allp))
+    assert dt.item() >= 0.01 * (world - 1)
+    if rank == 0:
+        print("GATHER_OK", world, len(allp), hashlib.sha256(b"".join(allp)).hexdigest())
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29531", str(script)],
+        capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    want = hashlib.sha256(b"".join(hashlib.sha256(b"proof-%d" % j).digest() for j in range(11))).hexdigest()
+    assert "GATHER_OK 2 11 " + want in out.stdout

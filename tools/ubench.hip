@@ -28,7 +28,7 @@ constexpr int ITERS = 4096;
     uint32_t b = a0 | 0x80000001u;                                                          \
     for (int i = 0; i < ITERS; ++i) {                                                       \
       asm volatile(ASM8 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),       \
-                   "+v"(a6), "+v"(a7) : "v"(b));                                            \
+                   "+v"(a6), "+v"(a7) : "v"(b) : "vcc", "s10","s11","s12","s13","s14","s15","s16","s17","s18","s19","s20","s21","s22","s23","s24","s25","s26","s27"); \
     }                                                                                       \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;     \
   }
@@ -47,6 +47,45 @@ PROBE(k_addc, "v_add_co_u32 %0, vcc, %0, %8\n v_addc_co_u32 %1, vcc, %1, %8, vcc
               "v_addc_co_u32 %4, vcc, %4, %8, vcc\n v_addc_co_u32 %5, vcc, %5, %8, vcc\n v_addc_co_u32 %6, vcc, %6, %8, vcc\n v_addc_co_u32 %7, vcc, %7, %8, vcc\n")
 PROBE(k_dot4, "v_dot4_u32_u8 %0, %0, %8, %1\n v_dot4_u32_u8 %1, %1, %8, %2\n v_dot4_u32_u8 %2, %2, %8, %3\n v_dot4_u32_u8 %3, %3, %8, %4\n"
               "v_dot4_u32_u8 %4, %4, %8, %5\n v_dot4_u32_u8 %5, %5, %8, %6\n v_dot4_u32_u8 %6, %6, %8, %7\n v_dot4_u32_u8 %7, %7, %8, %0\n")
+
+
+PROBE(k_addco, "v_add_co_u32 %0, s[10:11], %0, %8\n v_add_co_u32 %1, s[12:13], %1, %8\n v_add_co_u32 %2, s[14:15], %2, %8\n v_add_co_u32 %3, s[16:17], %3, %8\n"
+               "v_add_co_u32 %4, s[18:19], %4, %8\n v_add_co_u32 %5, s[20:21], %5, %8\n v_add_co_u32 %6, s[22:23], %6, %8\n v_add_co_u32 %7, s[24:25], %7, %8\n")
+// addc with independent carry registers written far earlier (no VALU->SGPR->VALU hazard inside the loop)
+PROBE(k_addc_indep, "v_addc_co_u32 %0, s[10:11], %0, %8, s[26:27]\n v_addc_co_u32 %1, s[12:13], %1, %8, s[26:27]\n v_addc_co_u32 %2, s[14:15], %2, %8, s[26:27]\n v_addc_co_u32 %3, s[16:17], %3, %8, s[26:27]\n"
+                    "v_addc_co_u32 %4, s[18:19], %4, %8, s[26:27]\n v_addc_co_u32 %5, s[20:21], %5, %8, s[26:27]\n v_addc_co_u32 %6, s[22:23], %6, %8, s[26:27]\n v_addc_co_u32 %7, s[24:25], %7, %8, s[26:27]\n")
+PROBE(k_mov, "v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %8\n")
+PROBE(k_cndmask, "v_cndmask_b32 %0, %0, %8, s[26:27]\n v_cndmask_b32 %1, %1, %8, s[26:27]\n v_cndmask_b32 %2, %2, %8, s[26:27]\n v_cndmask_b32 %3, %3, %8, s[26:27]\n"
+                 "v_cndmask_b32 %4, %4, %8, s[26:27]\n v_cndmask_b32 %5, %5, %8, s[26:27]\n v_cndmask_b32 %6, %6, %8, s[26:27]\n v_cndmask_b32 %7, %7, %8, s[26:27]\n")
+PROBE(k_add3, "v_add3_u32 %0, %0, %8, %1\n v_add3_u32 %1, %1, %8, %2\n v_add3_u32 %2, %2, %8, %3\n v_add3_u32 %3, %3, %8, %4\n"
+              "v_add3_u32 %4, %4, %8, %5\n v_add3_u32 %5, %5, %8, %6\n v_add3_u32 %6, %6, %8, %7\n v_add3_u32 %7, %7, %8, %0\n")
+PROBE(k_xor, "v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n")
+PROBE(k_alignbit, "v_alignbit_b32 %0, %0, %0, 7\n v_alignbit_b32 %1, %1, %1, 7\n v_alignbit_b32 %2, %2, %2, 7\n v_alignbit_b32 %3, %3, %3, 7\n v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n v_alignbit_b32 %7, %7, %7, 7\n")
+// one dependent chain of v_mad_u64_u32 per lane: latency
+__global__ void __launch_bounds__(256) k_mad64_dep(uint32_t* out, uint32_t seed) {
+  uint64_t a0 = threadIdx.x + seed;
+  uint32_t b = (uint32_t)a0 | 0x80000001u, c = b * 77 + 5;
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile(
+        "v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n"
+        "v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n"
+        "v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n"
+        "v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n v_mad_u64_u32 %0, s[10:11], %1, %2, %0\n"
+        : "+v"(a0) : "v"(b), "v"(c) : "s10", "s11");
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0 ^ (uint32_t)(a0 >> 32);
+}
+__global__ void __launch_bounds__(256) k_lshladd64(uint32_t* out, uint32_t seed) {
+  uint64_t a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, b = a0 * 0x9e3779b97f4a7c15ull;
+  for (int i = 0; i < ITERS; ++i) {
+    asm volatile(
+        "v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0, %4\n v_lshl_add_u64 %2, %2, 0, %4\n v_lshl_add_u64 %3, %3, 0, %4\n"
+        "v_lshl_add_u64 %0, %0, 0, %4\n v_lshl_add_u64 %1, %1, 0, %4\n v_lshl_add_u64 %2, %2, 0, %4\n v_lshl_add_u64 %3, %3, 0, %4\n"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+  }
+  uint64_t r = a0 ^ a1 ^ a2 ^ a3;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32);
+}
 
 // v_mad_u64_u32: 4 independent 64-bit accumulator chains per lane (8 VGPRs)
 __global__ void __launch_bounds__(256) k_mad64(uint32_t* out, uint32_t seed) {
@@ -257,7 +296,10 @@ int main() {
     int per_iter;
   } probes[] = {{"v_mul_lo_u32", k_mul_lo, 8},       {"v_mul_hi_u32", k_mul_hi, 8}, {"v_mad_u32_u24", k_mad24, 8},
                 {"v_mul_hi_u32_u24", k_mulhi24, 8}, {"v_add_u32", k_add, 8},       {"v_add(c)_co_u32", k_addc, 8},
-                {"v_dot4_u32_u8", k_dot4, 8},        {"v_mad_u64_u32", k_mad64, 8}, {"v_fma_f64", k_fma64, 8}};
+                {"v_dot4_u32_u8", k_dot4, 8},        {"v_mad_u64_u32", k_mad64, 8}, {"v_fma_f64", k_fma64, 8},
+                {"v_add_co_u32 (indep)", k_addco, 8}, {"v_addc_co_u32 (indep)", k_addc_indep, 8}, {"v_mov_b32", k_mov, 8},
+                {"v_cndmask_b32", k_cndmask, 8}, {"v_add3_u32", k_add3, 8}, {"v_xor_b32", k_xor, 8}, {"v_alignbit_b32", k_alignbit, 8},
+                {"v_mad_u64_u32 dep chain", k_mad64_dep, 8}, {"v_lshl_add_u64", k_lshladd64, 8}};
   for (auto& p : probes) {
     double s = time_kernel([&] { hipLaunchKernelGGL(p.k, dim3(blocks), dim3(threads), 0, 0, dout, 1u); });
     double lane_ops = (double)nthreads * ITERS * p.per_iter;
