@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstarkhip.so")
+LIB_PATH = os.environ.get("STARKHIP_LIB") or os.path.join(_HERE, "libstarkhip.so")
 
 MIMC_P = 2**256 - 2**32 * 351 + 1  # starks/utils.py:22
 

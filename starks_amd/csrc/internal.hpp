@@ -28,7 +28,7 @@ struct NttPassArgs {
 // Launch one tile pass (radix 2^log_R).  Returns hipSuccess or the launch error.
 hipError_t shk_launch_ntt_pass(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
 hipError_t shk_launch_ntt_tiny(const fp* src, fp* dst, uint32_t n, uint32_t batch, const fp* scale, hipStream_t st);
-constexpr int SHK_TILE_LOG = 11;  // 2048 elements (64 KiB of LDS) per workgroup
+constexpr int SHK_TILE_LOG = 10;  // default tile: 1024 elements (32 KiB of LDS, 256 threads) per workgroup -> 5 workgroups per CU
 
 // ---- kernels.hip: conversions, powers, Merkle, FRI fold, sampling, branch gather ------------------
 hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st);

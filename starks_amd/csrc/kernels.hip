@@ -103,6 +103,26 @@ __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, 
   }
 }
 
+
+// Wide levels: one thread reduces 4 adjacent nodes of level L to their parent pair (level L-1) and
+// grandparent (level L-2): every lane busy, three hashes per thread (two independent, one dependent).
+__global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t batch) {
+  const uint64_t cnt = 1ull << (L - 2);  // nodes produced at level L-2, per tree
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= cnt * batch) return;
+  const uint64_t b = g / cnt, i = g - b * cnt;
+  uint32_t* tree = nodes + b * (2 * n) * 8;
+  uint32_t w[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load8(tree + ((1ull << L) + 4 * i + j) * 8, w[j]);
+  b2digest d0 = b2_hash_pair(w[0], w[1]);
+  b2digest d1 = b2_hash_pair(w[2], w[3]);
+  store8(tree + ((1ull << (L - 1)) + 2 * i) * 8, d0.h);
+  store8(tree + ((1ull << (L - 1)) + 2 * i + 1) * 8, d1.h);
+  b2digest d2 = b2_hash_pair(d0.h, d1.h);
+  store8(tree + (cnt + i) * 8, d2.h);
+}
+
 // Reduces 512 nodes of level L to one node of level L-9, writing every level on the way:
 // one hash per thread from global memory, six levels inside each wavefront through lane shuffles
 // (the per-wave Merkle-pair reduction), the last two through LDS.
@@ -321,6 +341,14 @@ hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint
   uint32_t logn = 0;
   while ((1ull << logn) < n) ++logn;
   int L = (int)logn - 2;
+  // wide levels: two levels per launch at full lane efficiency, while a level still fills the chip
+  while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << 15)) {
+    const uint64_t work = (1ull << (L - 2)) * batch;
+    hipLaunchKernelGGL(merkle_mid_kernel, dim3(grid_for(work)), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L, batch);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    L -= 2;
+  }
   while (L > 0) {
     const uint64_t cnt = 1ull << (L - 1);
     hipLaunchKernelGGL(merkle_upper_kernel, dim3(grid_for(cnt), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);

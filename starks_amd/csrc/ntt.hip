@@ -1,13 +1,15 @@
 // ntt.hip -- instantiations and launchers of the NTT tile passes (ntt_kernels.cuh).
+#include <stdlib.h>
+
 #include "ntt_kernels.cuh"
 
 namespace {
 
-template <int LOG_R, bool LAST>
-hipError_t launch(const NttPassArgs& a, hipStream_t st) {
-  constexpr int LOG_T = SHK_TILE_LOG - LOG_R;
-  constexpr int THREADS = 1 << (SHK_TILE_LOG - 2);
-  constexpr size_t LDS = (size_t)32 << SHK_TILE_LOG;
+template <int LOG_R, bool LAST, int TILE_LOG>
+hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
+  constexpr int LOG_T = TILE_LOG - LOG_R;
+  constexpr int THREADS = 1 << (TILE_LOG - 2);
+  constexpr size_t LDS = (size_t)32 << TILE_LOG;
   auto k = ntt_pass_kernel<LOG_R, LOG_T, LAST>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -21,6 +23,23 @@ hipError_t launch(const NttPassArgs& a, hipStream_t st) {
   if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(THREADS), LDS, st, a);
   return hipGetLastError();
+}
+
+int tile_log_choice() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_TILE_LOG");
+    v = e ? atoi(e) : SHK_TILE_LOG;
+    if (v != 9 && v != 10 && v != 11) v = SHK_TILE_LOG;
+  }
+  return v;
+}
+
+template <int LOG_R, bool LAST>
+hipError_t launch(const NttPassArgs& a, hipStream_t st) {
+  if (tile_log_choice() == 10) return launch_tile<LOG_R, LAST, 10>(a, st);
+  if (tile_log_choice() == 9) return launch_tile<LOG_R, LAST, 9>(a, st);
+  return launch_tile<LOG_R, LAST, 11>(a, st);
 }
 
 template <bool LAST>

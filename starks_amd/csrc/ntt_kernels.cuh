@@ -159,8 +159,11 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   }
 }
 
+#ifndef SHK_NTT_MIN_WAVES
+#define SHK_NTT_MIN_WAVES 4
+#endif
 template <int LOG_R, int LOG_T, bool LAST>
-__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2)) ntt_pass_kernel(NttPassArgs a) {
+__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) ntt_pass_kernel(NttPassArgs a) {
   static_assert(LOG_R >= 2 && LOG_R <= 8 && LOG_R + LOG_T >= 8, "unsupported tile");
   constexpr int G = (LOG_R + 1) / 2;  // register groups (two levels each, the last may have one)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];

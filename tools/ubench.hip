@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "fp256.cuh"
+#include "fp29.cuh"
 
 #define CK(x)                                                                      \
   do {                                                                             \
@@ -166,6 +167,46 @@ __global__ void __launch_bounds__(256) k_fpbfly(const fp* in, fp* out) {
     y = d;
   }
   out[gid] = fp_add(x, y);
+}
+
+
+// ---- unsaturated 9 x 29 arithmetic (fp29.cuh) -------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_f29mul(const fp* in, fp* out) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  fp29 a = f29_from_fp(in[gid * 2]);
+  fp29 w = f29_balanced_from_fp(fp_canon(in[gid * 2 + 1]));
+  for (int i = 0; i < FITERS; ++i) a = f29_mul(a, w);
+  out[gid] = f29_to_fp(a);
+}
+// DIT butterfly chain: t = w*y ; (x, y) <- (x + t, x - t); digits renormalised every 4 levels
+__global__ void __launch_bounds__(256) k_f29bfly(const fp* in, fp* out) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  fp29 x = f29_from_fp(in[gid * 2]), y = f29_from_fp(in[gid * 2 + 1]);
+  fp29 w = f29_balanced_from_fp(fp_canon(in[(gid * 2 + 3) % 1024]));
+  for (int i = 0; i < FITERS; i += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      fp29 t = f29_mul(y, w);
+      fp29 s = f29_add(x, t);
+      y = f29_sub(x, t);
+      x = s;
+    }
+    x = f29_normalize(x);
+    y = f29_normalize(y);
+  }
+  out[gid] = f29_to_fp(f29_add(x, y));
+}
+__global__ void k_f29check(const fp* in, fp* out, int n) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  fp a = in[gid * 2], b = fp_canon(in[gid * 2 + 1]);
+  fp29 xa = f29_from_fp(a), wb = f29_balanced_from_fp(b);
+  fp29 m = f29_mul(xa, wb);
+  out[gid * 4 + 0] = fp_canon(f29_to_fp(m));                                 // a*b
+  out[gid * 4 + 1] = fp_canon(f29_to_fp(f29_add(xa, m)));                    // a + a*b
+  out[gid * 4 + 2] = fp_canon(f29_to_fp(f29_sub(xa, m)));                    // a - a*b
+  fp29 d = f29_sub(f29_sub(f29_sub(xa, m), m), m);                           // a - 3ab (lazy, negative limbs)
+  out[gid * 4 + 3] = fp_canon(f29_to_fp(f29_mul(f29_normalize(d), wb)));     // (a - 3ab) * b
 }
 
 __global__ void k_fpcheck(const fp* in, fp* out, int n) {
@@ -351,6 +392,27 @@ int main() {
   }
   printf("fp256 device check: %d mismatches of %d; host-build check: %d mismatches\n", bad, NCHK * 4, hbad);
 
+
+  // ---- fp29 correctness on device vs host reference ----
+  {
+    hipLaunchKernelGGL(k_f29check, dim3((NCHK + 255) / 256), dim3(256), 0, 0, din, dres, NCHK);
+    CK(hipMemcpy(hres.data(), dres, sizeof(fp) * NCHK * 4, hipMemcpyDeviceToHost));
+    int bad29 = 0;
+    for (int i = 0; i < NCHK; ++i) {
+      H256 a = hcanon(from_fp(hin[2 * i])), b = hcanon(from_fp(hin[2 * i + 1]));
+      H256 ab = hmul(a, b);
+      H256 a3 = hsub(hsub(hsub(a, ab), ab), ab);
+      H256 e[4] = {ab, hadd(a, ab), hsub(a, ab), hmul(a3, b)};
+      for (int k = 0; k < 4; ++k)
+        if (hcmp(from_fp(hres[4 * i + k]), e[k]) != 0) {
+          if (bad29 < 10) printf("F29 MISMATCH case %d op %d\n", i, k);
+          ++bad29;
+        }
+    }
+    printf("fp29 device check: %d mismatches of %d\n", bad29, NCHK * 4);
+    bad += bad29;
+  }
+
   // ---- fp256 throughput ----
   std::vector<fp> big(nthreads * 2);
   for (size_t i = 0; i < nthreads * 2; ++i)
@@ -363,9 +425,11 @@ int main() {
     double s2 = time_kernel([&] { hipLaunchKernelGGL(k_fpmul<2>, dim3(bl), dim3(threads), 0, 0, din, dres); });
     double s3 = time_kernel([&] { hipLaunchKernelGGL(k_fpbfly, dim3(bl), dim3(threads), 0, 0, din, dres); });
     double s4 = time_kernel([&] { hipLaunchKernelGGL(k_fpaddsub, dim3(bl), dim3(threads), 0, 0, din, dres); });
-    printf("blocks/CU=%d  modmul x1: %7.2f G/s   x2: %7.2f G/s   butterfly: %7.2f G/s   add+sub pair: %7.2f G/s\n", wpb,
+    double s5 = time_kernel([&] { hipLaunchKernelGGL(k_f29mul, dim3(bl), dim3(threads), 0, 0, din, dres); });
+    double s6 = time_kernel([&] { hipLaunchKernelGGL(k_f29bfly, dim3(bl), dim3(threads), 0, 0, din, dres); });
+    printf("blocks/CU=%d  modmul x1: %7.2f G/s   x2: %7.2f G/s   butterfly: %7.2f G/s   add+sub pair: %7.2f G/s | f29 mul: %7.2f G/s  f29 DIT butterfly: %7.2f G/s\n", wpb,
            (double)nt * FITERS / s1 * 1e-9, (double)nt * FITERS * 2 / s2 * 1e-9, (double)nt * FITERS / s3 * 1e-9,
-           (double)nt * FITERS / s4 * 1e-9);
+           (double)nt * FITERS / s4 * 1e-9, (double)nt * FITERS / s5 * 1e-9, (double)nt * FITERS / s6 * 1e-9);
   }
   return bad || hbad;
 }
