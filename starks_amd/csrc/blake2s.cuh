@@ -106,3 +106,75 @@ B2_HD b2digest b2_hash_short(const uint32_t m[16], uint32_t len) {
   b2_compress(d.h, m, len, true);
   return d;
 }
+
+// ---- quad-lane BLAKE2s (device only) ---------------------------------------------------------------------
+// Four adjacent lanes (a "quad", q = lane & 3) compute ONE compression together: lane q owns column q of the
+// 4 x 4 state (a = v[q], b = v[4+q], c = v[8+q], d = v[12+q]); the diagonal step is the column step after
+// rotating rows b, c, d by 1, 2, 3 lanes inside the quad, which DPP quad_perm does inside the VALU (no LDS).
+// The 16 message words sit in a 64-byte LDS slot owned by the quad; each lane reads the 4 words per round it
+// needs through 40 byte addresses it keeps in registers (b2q_addr_init).  One compression costs ~1/3 of the
+// single-lane instruction stream per lane, i.e. ~3.5x lower latency -- used where the Merkle tree / the
+// Fiat-Shamir chain is a serial dependency (top of the tree, index sampling), not where it is throughput bound.
+#if defined(__HIPCC__)
+struct b2q_addr {
+  uint32_t a[40];  // LDS byte addresses of m[sigma[r][2q]], m[sigma[r][2q+1]], m[sigma[r][8+2q]], m[sigma[r][9+2q]]
+};
+
+__device__ __forceinline__ uint32_t b2q_sigma(int r, int i) {
+  // sigma rows packed 4 bits per entry (entry i in bits [4i, 4i+4))
+  const uint64_t S[10] = {0xfedcba9876543210ull, 0x357b20c16df984aeull, 0x491763eadf250c8bull, 0x8f04a562ebcd1397ull,
+                          0xd386cb1efa427509ull, 0x91ef57d438b0a6c2ull, 0xb8293670a4def15cull, 0xa2684f05931ce7bdull,
+                          0x5a417d2c803b9ef6ull, 0x0dc3e9bf5167482aull};
+  return (uint32_t)(S[r] >> (4 * i)) & 15u;
+}
+
+// slot_base: LDS byte address of this quad's 64-byte message slot
+__device__ __forceinline__ void b2q_addr_init(b2q_addr& t, uint32_t slot_base, uint32_t q) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // k = 0,1: column step words 2q, 2q+1 ; k = 2,3: diagonal step words 8+2q, 9+2q
+      const int basei = (k < 2 ? 0 : 8) + (k & 1);
+      uint32_t idx = b2q_sigma(r, basei);  // q = 0
+      idx = q == 1 ? b2q_sigma(r, basei + 2) : idx;
+      idx = q == 2 ? b2q_sigma(r, basei + 4) : idx;
+      idx = q == 3 ? b2q_sigma(r, basei + 6) : idx;
+      t.a[4 * r + k] = slot_base + 4 * idx;
+    }
+  }
+}
+
+#define B2Q_DPP(x, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xf, 0xf, false))
+
+// Compress the 64-byte block in the quad's LDS slot (byte counter tcount, final block).  `slots` = the LDS array
+// the byte offsets in `t` are relative to.  Returns this lane's two digest words: h[q] and h[4+q].
+__device__ __forceinline__ uint32_t b2q_word(const uint32_t* slots, uint32_t byte_off) {
+  return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(slots) + byte_off);
+}
+__device__ __forceinline__ void b2q_compress(const b2q_addr& t, const uint32_t* slots, uint32_t q, uint32_t tcount,
+                                             uint32_t& h_lo, uint32_t& h_hi) {
+  const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+  const uint32_t iv_hi = q == 0 ? 0x510E527Fu : q == 1 ? 0x9B05688Cu : q == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+  const uint32_t h0_lo = iv_lo ^ (q == 0 ? 0x01010020u : 0u);
+  const uint32_t h0_hi = iv_hi;
+  uint32_t a = h0_lo, b = h0_hi, c = iv_lo;
+  uint32_t d = iv_hi ^ (q == 0 ? tcount : q == 2 ? 0xffffffffu : 0u);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t mx = b2q_word(slots, t.a[4 * r + 0]), my = b2q_word(slots, t.a[4 * r + 1]);
+    B2_G(a, b, c, d, mx, my);
+    b = B2Q_DPP(b, 0x39);  // lane q <- lane (q+1)&3
+    c = B2Q_DPP(c, 0x4e);  // lane q <- lane (q+2)&3
+    d = B2Q_DPP(d, 0x93);  // lane q <- lane (q+3)&3
+    mx = b2q_word(slots, t.a[4 * r + 2]);
+    my = b2q_word(slots, t.a[4 * r + 3]);
+    B2_G(a, b, c, d, mx, my);
+    b = B2Q_DPP(b, 0x93);
+    c = B2Q_DPP(c, 0x4e);
+    d = B2Q_DPP(d, 0x39);
+  }
+  h_lo = h0_lo ^ a ^ c;
+  h_hi = h0_hi ^ b ^ d;
+}
+#endif  // __HIPCC__

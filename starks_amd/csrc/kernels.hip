@@ -123,65 +123,39 @@ __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64
   store8(tree + (cnt + i) * 8, d2.h);
 }
 
-// Reduces 512 nodes of level L to one node of level L-9, writing every level on the way:
-// one hash per thread from global memory, six levels inside each wavefront through lane shuffles
-// (the per-wave Merkle-pair reduction), the last two through LDS.
-__global__ void __launch_bounds__(TPB) merkle_upper_kernel(uint32_t* nodes, uint64_t n, uint32_t L) {
-  __shared__ uint32_t wave_out[4][8];
+// Top of the tree, where each level waits for the one below: a workgroup of 64 quads reduces 2^levels (<= 128)
+// adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent,
+// children handed up through the quads' LDS message slots.  ~1 us per level instead of ~3.3 us.
+__global__ void __launch_bounds__(TPB) merkle_top_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t levels) {
+  __shared__ __attribute__((aligned(16))) uint32_t slots[64 * 16];
   uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  uint32_t lvl = L - 1;
-  uint64_t idx = (uint64_t)blockIdx.x * TPB + tid;
-  b2digest d;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) d.h[k] = 0;
-  if (idx < (1ull << lvl)) {
-    uint32_t l[8], r[8];
-    load8(tree + ((1ull << L) + 2 * idx) * 8, l);
-    load8(tree + ((1ull << L) + 2 * idx + 1) * 8, r);
-    d = b2_hash_pair(l, r);
-    store8(tree + ((1ull << lvl) + idx) * 8, d.h);
+  const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
+  b2q_addr ad;
+  b2q_addr_init(ad, quad * 64, q);
+  uint32_t active = 1u << (levels - 1);  // quads hashing in this step
+  if (quad < active) {
+    const uint64_t node = (1ull << L) + ((uint64_t)blockIdx.x << levels) + 2 * quad;
+    const uint4 v = *reinterpret_cast<const uint4*>(tree + node * 8 + 4 * q);  // 16 of the pair's 64 bytes
+    *reinterpret_cast<uint4*>(slots + quad * 16 + 4 * q) = v;
   }
-  // in-wave levels
-  uint64_t wbase = (uint64_t)blockIdx.x * TPB + wave * 64;  // node index of lane 0 at the current level
-#pragma unroll
-  for (int s = 1; s <= 6; ++s) {
-    if (lvl == 0) break;
+  uint32_t lvl = L;
+  for (uint32_t s = 0; s < levels; ++s) {
+    __syncthreads();  // message slots written
+    uint32_t h_lo = 0, h_hi = 0;
     lvl -= 1;
-    wbase >>= 1;
-    uint32_t l[8], r[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      l[k] = __shfl(d.h[k], (int)((2 * lane) & 63));
-      r[k] = __shfl(d.h[k], (int)((2 * lane + 1) & 63));
+    if (quad < active) {
+      b2q_compress(ad, slots, q, 64, h_lo, h_hi);
+      uint32_t* out = tree + ((1ull << lvl) + ((uint64_t)blockIdx.x << (levels - 1 - s)) + quad) * 8;
+      out[q] = h_lo;
+      out[4 + q] = h_hi;
     }
-    if (lane < (64u >> s) && wbase + lane < (1ull << lvl)) {
-      d = b2_hash_pair(l, r);
-      store8(tree + ((1ull << lvl) + wbase + lane) * 8, d.h);
+    __syncthreads();  // everyone has read its slot: parents' slots may be overwritten
+    if (quad < active) {
+      uint32_t* dst = slots + (quad >> 1) * 16 + 8 * (quad & 1);
+      dst[q] = h_lo;
+      dst[4 + q] = h_hi;
     }
-  }
-  if (lvl == 0) return;  // uniform per block: all lanes see the same lvl
-  // across the 4 waves
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wave_out[wave][k] = d.h[k];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  lvl -= 1;  // level L-8: two nodes per block
-  uint64_t bbase = (uint64_t)blockIdx.x * 2;
-  if (lane < 2 && bbase + lane < (1ull << lvl)) {
-    d = b2_hash_pair(wave_out[2 * lane], wave_out[2 * lane + 1]);
-    store8(tree + ((1ull << lvl) + bbase + lane) * 8, d.h);
-  }
-  if (lvl == 0) return;
-  lvl -= 1;  // level L-9: one node per block
-  uint32_t r[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) r[k] = __shfl(d.h[k], 1);
-  if (lane == 0 && blockIdx.x < (1ull << lvl)) {
-    b2digest e = b2_hash_pair(d.h, r);
-    store8(tree + ((1ull << lvl) + blockIdx.x) * 8, e.h);
+    active >>= 1;
   }
 }
 
@@ -222,30 +196,47 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
 }
 
 // ---- query sampling + branch gather --------------------------------------------------------------------
-// get_pseudorandom_indices(m2[1], q, samples, exclude_multiples_of) (utils.py:60-90), one thread per proof.
-__global__ void fri_sample_kernel(SampleArgs a) {
-  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.batch) return;
-  const uint64_t q = a.n >> 2;
-  uint32_t blk[16];
-  load8(a.nodes_m2 + ((uint64_t)b * 2 * q + 1) * 8, blk);  // entropy = root of the column tree
-#pragma unroll
-  for (int k = 8; k < 16; ++k) blk[k] = 0;
-  const uint32_t modulus = (uint32_t)q;
+// get_pseudorandom_indices(m2[1], q, samples, exclude_multiples_of) (utils.py:60-90): one QUAD of lanes per proof.
+// data = root, then data += blake(data[-32:]) (utils.py:74-75): a serial chain, so each 32-byte block is hashed
+// with the low-latency quad-lane BLAKE2s; after block k lane q holds words q and 4+q = samples 8k+q and 8k+4+q.
+__global__ void __launch_bounds__(64) fri_sample_kernel(SampleArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t slots[16 * 16];
+  const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
+  const uint32_t b = blockIdx.x * 16 + quad;
+  const bool live = b < a.batch;
+  const uint64_t qn = a.n >> 2;
+  b2q_addr ad;
+  b2q_addr_init(ad, quad * 64, q);
+  uint32_t w_lo = 0, w_hi = 0;
+  if (live) {
+    const uint32_t* root = a.nodes_m2 + ((uint64_t)b * 2 * qn + 1) * 8;  // entropy = root of the column tree
+    w_lo = root[q];
+    w_hi = root[4 + q];
+  }
+  uint32_t* slot = slots + quad * 16;
+  slot[8 + q] = 0;   // a 32-byte message: words 8..15 are zero padding
+  slot[12 + q] = 0;
+  const uint32_t modulus = (uint32_t)qn;
   const uint32_t real = a.exclude ? (uint32_t)(((uint64_t)modulus * (a.exclude - 1)) / a.exclude) : modulus;
   uint32_t* ys = a.ys + (uint64_t)b * a.samples;
-  for (uint32_t j = 0; j < a.samples; ++j) {
-    if (j && (j & 7) == 0) {  // data += blake(data[-32:])  (utils.py:74-75)
-      b2digest d = b2_hash_short(blk, 32);
+  const uint32_t blocks = (a.samples + 7) / 8;
+  for (uint32_t k = 0; k < blocks; ++k) {
+    if (live) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) blk[k] = d.h[k];
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t j = 8 * k + 4 * half + q;
+        if (j < a.samples) {
+          const uint32_t x = __builtin_bswap32(half ? w_hi : w_lo) % real;  // int.from_bytes(data[4j:4j+4], 'big') % modulus
+          ys[j] = a.exclude ? x + 1 + x / (a.exclude - 1) : x;
+        }
+      }
     }
-    uint32_t word = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if ((j & 7) == (uint32_t)k) word = blk[k];
-    const uint32_t x = __builtin_bswap32(word) % real;  // int.from_bytes(data[i:i+4], 'big') % modulus
-    ys[j] = a.exclude ? x + 1 + x / (a.exclude - 1) : x;
+    if (k + 1 == blocks) break;
+    slot[q] = w_lo;
+    slot[4 + q] = w_hi;
+    __syncthreads();
+    b2q_compress(ad, slots, q, 32, w_lo, w_hi);
+    __syncthreads();
   }
 }
 // mk_branch (merkle_tree.py:59-68) for the 5 branches of every sample, written into the flat proof.
@@ -350,11 +341,12 @@ hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint
     L -= 2;
   }
   while (L > 0) {
-    const uint64_t cnt = 1ull << (L - 1);
-    hipLaunchKernelGGL(merkle_upper_kernel, dim3(grid_for(cnt), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
+    const int levels = L > 7 ? 7 : L;
+    hipLaunchKernelGGL(merkle_top_kernel, dim3(1u << (L - levels), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L,
+                       (uint32_t)levels);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    L = L > 9 ? L - 9 : 0;
+    L -= levels;
   }
   return hipSuccess;
 }
@@ -365,7 +357,7 @@ hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(fri_sample_kernel, dim3((a.batch + 63) / 64), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(fri_sample_kernel, dim3((a.batch + 15) / 16), dim3(64), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   uint32_t l1 = 1, l2;

@@ -4,7 +4,10 @@ import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import Dev, root_of
 dev = Dev(); L, ctx = dev.L, dev.ctx
-for logsteps, batch in [(14, 1), (14, 16), (16, 1), (16, 16), (20, 1)]:
+cfgs = [(14, 1), (14, 16), (16, 1), (16, 16), (20, 1)]
+if len(sys.argv) > 1:
+    cfgs = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]]
+for logsteps, batch in cfgs:
     steps, ext = 1 << logsteps, 8
     n = steps * ext
     w = root_of(n).to_bytes(32, "big")
