@@ -153,19 +153,27 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--quick", action="store_true", help="smaller secondary legs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
+                    "the N > 1 path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    os.environ.setdefault("STARKHIP_DEVICE", str(local_rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    os.environ["STARKHIP_DEVICE"] = str(dev_index)
+    torch.cuda.set_device(dev_index)
+    tdev = "cuda" if args.backend == "nccl" else "cpu"  # where the tiny control tensors live
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     dev = Dev()
     L, ctx = dev.L, dev.ctx
@@ -196,7 +204,7 @@ def main():
     dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev_ms)), "timer")  # HIP events on the library's stream
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
@@ -217,7 +225,7 @@ def main():
             golden_ok = hit[0]["sha_fwd"] == fwd_digest
     except Exception:
         pass
-    ok = torch.tensor([1 if roundtrip_ok and golden_ok is not False else 0], device="cuda")
+    ok = torch.tensor([1 if roundtrip_ok and golden_ok is not False else 0], device=tdev)
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the only exchange: a 1-word status gather over RCCL
 

@@ -327,3 +327,81 @@ def test_device_resident_pipeline(sa, oracle):
     assert host.raw == wire(seeded(0x5eed, i) for i in range(n))
     for d in (d_x, d_y, d_t):
         assert L.sh_dev_free(ctx, d) == 0
+
+
+# ---- BASELINE.json full sizes through size-independent properties ------------------------------------------
+def test_full_size_ntt_2_24_roundtrip(sa):
+    """Config 4: 2^24-point NTT (512 MiB vector, three radix-256 passes): invNTT(NTT(x)) == x bit for bit."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << 24
+    w = root_of(n).to_bytes(32, "big")
+    dx, dy = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dx)) == 0 and L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dy)) == 0
+    assert L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed) == 0
+    assert L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0) == 0
+    a = ctypes.create_string_buffer(32 * 4096)
+    assert L.sh_dev_to_wire(ctx, dy, a, 4096) == 0
+    fwd_head = a.raw
+    assert L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1) == 0
+    x, y = ctypes.create_string_buffer(32 * n), ctypes.create_string_buffer(32 * n)
+    assert L.sh_dev_to_wire(ctx, dx, x, n) == 0 and L.sh_dev_to_wire(ctx, dy, y, n) == 0
+    assert hashlib.sha256(x.raw).digest() == hashlib.sha256(y.raw).digest()
+    assert x.raw[:64] == wire([seeded(0x5eed, 0), seeded(0x5eed, 1)])
+    # out[0] = sum of the inputs: check against a host sum over the downloaded vector
+    xs = x.raw
+    total = 0
+    for off in range(0, len(xs), 32 * 65536):
+        blk = xs[off:off + 32 * 65536]
+        total += sum(int.from_bytes(blk[i:i + 32], "big") for i in range(0, len(blk), 32))
+    assert int.from_bytes(fwd_head[:32], "big") == total % P
+    assert L.sh_dev_free(ctx, dx) == 0 and L.sh_dev_free(ctx, dy) == 0
+
+
+@pytest.mark.parametrize("logsteps", [16, 20])
+def test_full_size_fri_prove_then_verify(sa, logsteps):
+    """Config 5's proof size (2^16 steps, N = 2^19) and the metric's 2^20-step trace (N = 2^23): the GPU proof is
+    accepted by the host verifier (fri.py:268-366 semantics), and a corrupted one is rejected."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    steps, ext = 1 << logsteps, 8
+    n = steps * ext
+    g2 = root_of(n)
+    w = g2.to_bytes(32, "big")
+    dc, dv, dt = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dc)) == 0
+    assert L.sh_dev_fill_seeded(ctx, dc, steps, 0xabc) == 0                    # degree < steps polynomial
+    assert L.sh_dev_upload(ctx, bytes(32 * (n - steps)), ctypes.c_void_p(dc.value + 32 * steps), 32 * (n - steps)) == 0
+    plen = sa.fri.proof_len(n, steps, 40)
+    dp = ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, plen, ctypes.byref(dp)) == 0
+    assert L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, 1, dp) == 0
+    flat = ctypes.create_string_buffer(plen)
+    assert L.sh_dev_download(ctx, dp, flat, plen) == 0
+    proof = sa.fri.unpack_proof(flat.raw, n, steps, 40)
+    # the commitment the verifier starts from: root of the tree over the evaluations
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dv)) == 0 and L.sh_dev_alloc(ctx, 64 * n, ctypes.byref(dt)) == 0
+    assert L.sh_dev_ntt(ctx, dc, dv, n, 1, w, 0) == 0 and L.sh_dev_merkelize(ctx, dv, n, 1, dt) == 0
+    root = ctypes.create_string_buffer(64)
+    assert L.sh_dev_download(ctx, dt, root, 64) == 0
+    mroot = root.raw[32:64]
+    assert sa.fri.verify_low_degree_proof(proof, mroot, g2, steps, ext)
+    bad = [[proof[0][0], [[list(b) for b in bs] for bs in proof[0][1]]]] + proof[1:]
+    bad[0][1][7][2][0] = bytes(32)
+    with pytest.raises(AssertionError):
+        sa.fri.verify_low_degree_proof(bad, mroot, g2, steps, ext)
+    for d in (dc, dv, dt, dp):
+        assert L.sh_dev_free(ctx, d) == 0
+
+
+def test_batched_mimc_proofs_config5_shape(sa, oracle):
+    """starks_amd.batch: independent MiMC traces sharded by unit id; digests equal the one-at-a-time oracle proofs."""
+    from starks_amd import batch
+    steps = 256
+    units = list(batch.shard(6, 1, 2))  # rank 1 of 2 -> units 3, 4, 5
+    got = batch.prove_mimc_batch(units, steps, chunk=2)
+    assert [j for j, _ in got] == units
+    g2 = root_of(steps * 8)
+    for j, flat in got:
+        c = oracle.c.fft(oracle.py.mimc_trace(3 + j, steps), steps, pow(g2, 8, P), inverse=True)
+        assert flat == oracle.c.fri_prove_flat(wire(c), g2, steps, 8, 40)
