@@ -233,6 +233,15 @@ def main():
     value = elems_per_step * args.steps * world / dt_max
     alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
     achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_traffic.sh)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if args.logn == 20:
+            traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
+    except Exception:
+        pass
+    passes = 1 if args.logn <= 8 else (args.logn + 7) // 8
     line = {
         "metric": "ntt_field_elements_per_sec", "value": value, "unit": "elements/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -244,9 +253,13 @@ def main():
         "field_mul_eq_per_s": (n // 2) * args.logn * 2 * args.steps * world / dt_max,
         "check": {"roundtrip_ok": bool(int(ok.item())), "fwd_sha256": fwd_digest, "matches_reference_fixture": golden_ok},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "ntt_pass_kernel (3 launches per 2^20 transform)",
-                     "note": "integer-ALU bound: ~13 256-bit modmuls per element per transform; see DESIGN.md section 6"},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                     "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": 64.0 * n / passes,
+                     "kernel": "ntt_pass_kernel (%d launches per 2^%d transform)" % (passes, args.logn),
+                     "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
+                     "note": "integer-VALU bound, not HBM bound: ~11 256-bit modmuls + 20 add/sub per element per "
+                             "transform at ~95% of the half-rate VALU issue ceiling; see DESIGN.md section 5"},
     }
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int DIRECT_TABLE_LOG = 20;  // power tables up to 2^20 entries (32 MiB, L2/MALL resident) are stored in full
+constexpr int DIRECT_TABLE_LOG = 18;  // power tables up to 2^18 entries (8 MiB, L2-resident) are stored in full; larger ones as two halves
 
 // ---- host field helpers (the same fp256.cuh code the device runs) -----------------------------------
 fp h_from_wire(const uint8_t b[32]) {

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""profiles/<round>_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py` (tools/prof_traffic.sh).
+HBM bytes per launch of the dominant kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE
+reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact."""
+import csv, glob, json, sys, collections
+def per_kernel(root, counter):
+    f = glob.glob(root + "/*/*_counter_collection.csv")[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+def durations(root):
+    f = glob.glob(root + "/*/*_kernel_stats.csv")[0]
+    return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(f))}
+if __name__ == "__main__":
+    fdir, wdir, sdir, out = sys.argv[1:5]
+    F, W, D = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE"), durations(sdir)
+    res = {"workload": "bench.py default: 2^20-point NTT + inverse NTT", "unit": "bytes per launch",
+           "correction": "2*FETCH_SIZE + WRITE_SIZE, counters in KiB (gfx950: FETCH_SIZE = 1/2 of a wide coalesced stream)",
+           "kernels": {}}
+    tot_b = tot_n = 0
+    for k in F:
+        if "ntt_pass" not in k:
+            continue
+        fb = 2 * 1024 * sum(F[k]) / len(F[k])
+        wb = 1024 * sum(W[k]) / len(W[k])
+        calls, avg_ns = D.get(k, (len(F[k]), 0.0))
+        res["kernels"][k] = {"launches": len(F[k]), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb,
+                             "avg_duration_us_kernel_trace": avg_ns / 1e3}
+        tot_b += (fb + wb) * len(F[k])
+        tot_n += len(F[k])
+    res["ntt_pass_kernel_mean_hbm_bytes_per_launch"] = tot_b / tot_n
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
