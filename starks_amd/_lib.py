@@ -62,6 +62,7 @@ def lib():
         "sh_power_cycle": (i32, [c_p, u8p, u64, c_p]),
         "sh_lde": (i32, [c_p, u8p, c_p, u64, u32, u32, u8p]),
         "sh_merkelize": (i32, [c_p, u8p, u64, c_p]),
+        "sh_merkelize_packed": (i32, [c_p, u8p, u64, u32, c_p, c_p]),
         "sh_fri_fold": (i32, [c_p, u8p, u64, u8p, u8p, c_p]),
         "sh_fri_proof_len": (u64, [u64, u64, u32]),
         "sh_fri_prove": (i32, [c_p, u8p, u64, u64, u8p, u64, u32, u32, u32, c_p, u64]),

@@ -658,6 +658,23 @@ int sh_merkelize(sh_ctx* c, const uint8_t* leaves, uint64_t n, uint8_t* nodes) {
   return SH_OK;
 }
 
+int sh_merkelize_packed(sh_ctx* c, const uint8_t* evals, uint64_t n, uint32_t k, uint8_t* nodes, uint8_t* leaves) {
+  if (!c || !evals || !nodes || !leaves || !is_pow2(n) || n < 4 || k == 0) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  void *w = nullptr, *t = nullptr, *l = nullptr;
+  const size_t ebytes = (size_t)n * k * 32;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, ebytes, &w));
+  SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)2 * n * 32, &t));
+  SH_TRY(ws_get(c, sh_ctx::WS_X, ebytes, &l));
+  HIP_TRY(c, hipMemcpyAsync(w, evals, ebytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, shk_merkelize_packed(reinterpret_cast<const uint8_t*>(w), n, k, reinterpret_cast<uint8_t*>(l),
+                                  reinterpret_cast<uint32_t*>(t), c->stream));
+  HIP_TRY(c, hipMemcpyAsync(nodes, t, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(leaves, l, ebytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
+
 int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root[32], const uint8_t special_x[32],
                 uint8_t* column) {
   if (!c || !values || !root || !special_x || !column || !is_pow2(n) || n < 4) return SH_ERR_INVALID;

@@ -43,6 +43,10 @@ hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint3
 // Merkle tree of `batch` arrays of n limb-form values (or n raw 32-byte leaves when raw_leaves).
 hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
                          hipStream_t st);
+hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st);
+// packed leaves (merkle_tree.py:94-119): d_evals [k][n][32 B] wire; d_leaves [n][k][32 B] permuted; d_nodes [n][32 B]
+hipError_t shk_merkelize_packed(const uint8_t* d_evals, uint64_t n, uint32_t k, uint8_t* d_leaves, uint32_t* d_nodes,
+                                hipStream_t st);
 struct FoldArgs {
   const fp* values;        // [batch][n]
   const uint32_t* nodes;   // [batch][2n][8 words]; challenge = node 1 (nullptr: use special_x)

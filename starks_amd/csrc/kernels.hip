@@ -184,6 +184,43 @@ __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64
   store8(tree + (cnt + i) * 8, d2.h);
 }
 
+
+// Packed leaves (merkelize_polynomial_evaluations, merkle_tree.py:94-119): leaf x = evals[0][x] || ... || evals[k-1][x]
+// (32 k bytes), so a first-level node hashes a 64 k-byte message = k BLAKE2s blocks.  One thread per permute4 row.
+// evals: [k][n] wire-form values; leaves_out: [n][k] in permuted order (slot 4i+j = leaf i + j n/4); nodes: [n] x 32 B.
+__global__ void __launch_bounds__(TPB) merkle_packed_leaves_kernel(const uint32_t* evals, uint64_t n, uint32_t k,
+                                                                   uint32_t* leaves_out, uint32_t* nodes) {
+  const uint64_t q = n >> 2;
+  const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= q) return;
+  b2digest d[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    b2_init(d[s].h);
+    const uint64_t la = i + (uint64_t)(2 * s) * q, lb = i + (uint64_t)(2 * s + 1) * q;  // the pair's two leaves
+    for (uint32_t blk = 0; blk < k; ++blk) {
+      uint32_t m[16];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t e = 2 * blk + half;  // element index inside leafA || leafB
+        const uint64_t leaf = e < k ? la : lb;
+        const uint32_t c = e < k ? e : e - k;
+        load8(evals + ((uint64_t)c * n + leaf) * 8, m + 8 * half);
+        // the leaf itself (each element is loaded exactly once per pair)
+        store8(leaves_out + ((4 * i + 2 * s + (e < k ? 0 : 1)) * (uint64_t)k + c) * 8, m + 8 * half);
+      }
+      b2_compress(d[s].h, m, 64 * (blk + 1), blk + 1 == k);
+    }
+    store8(nodes + (n / 2 + 2 * i + s) * 8, d[s].h);
+  }
+  b2digest top = b2_hash_pair(d[0].h, d[1].h);
+  store8(nodes + (n / 4 + i) * 8, top.h);
+  if (i == 0) {
+    uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    store8(nodes, z);
+  }
+}
+
 // Top of the tree, where each level waits for the one below: a workgroup of 64 quads reduces 2^levels (<= 128)
 // adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent,
 // children handed up through the quads' LDS message slots.  ~1 us per level instead of ~3.3 us.
@@ -390,6 +427,11 @@ hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint
     hipLaunchKernelGGL(merkle_leaves_kernel<false>, lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  return shk_merkle_upper_levels(n, batch, d_nodes, st);
+}
+// levels log2(n)-2 .. 0 from the nodes the leaf kernels wrote (node layout of merkle_tree.py:36-56)
+hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st) {
+  hipError_t e = hipSuccess;
   uint32_t logn = 0;
   while ((1ull << logn) < n) ++logn;
   int L = (int)logn - 2;
@@ -431,4 +473,15 @@ hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* 
                          uint64_t off, hipStream_t st) {
   hipLaunchKernelGGL(fri_final_kernel, dim3(grid_for(n * batch)), dim3(TPB), 0, st, values, n, batch, proof, proof_stride, off);
   return hipGetLastError();
+}
+
+hipError_t shk_merkelize_packed(const uint8_t* d_evals, uint64_t n, uint32_t k, uint8_t* d_leaves, uint32_t* d_nodes,
+                                hipStream_t st) {
+  if (n < 4 || (n & (n - 1)) || k == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(merkle_packed_leaves_kernel, dim3(grid_for(n >> 2)), dim3(TPB), 0, st,
+                     reinterpret_cast<const uint32_t*>(d_evals), n, k, reinterpret_cast<uint32_t*>(d_leaves), d_nodes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // interior levels: the ordinary tree over n "virtual" 32-byte leaves; only the node half of the buffer is touched
+  return shk_merkle_upper_levels(n, 1, d_nodes, st);
 }

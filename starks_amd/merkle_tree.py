@@ -75,3 +75,28 @@ def verify_branch(root, index, proof, output_as_int=False):
         index //= 2
     assert v == root
     return int.from_bytes(proof[0], "big") if output_as_int else proof[0]
+
+
+def merkelize_polynomial_evaluations(dims, polynomial_evals):
+    """merkle_tree.py:94-119: one tree over several polynomials' evaluations; leaf x is the concatenation of every
+    polynomial's 32-byte value at x.  Returns the reference's list: 2n entries, [n:] are the (32 k)-byte leaves."""
+    k = len(polynomial_evals)
+    n = len(polynomial_evals[0])
+    if any(len(e) != n for e in polynomial_evals):
+        raise ValueError("all polynomials must be evaluated on the same domain")
+    if n < 4 or n & (n - 1):
+        raise NotImplementedError("starks_amd.merkelize needs a power-of-two number of leaves >= 4 (got %d)" % n)
+    data = b"".join(_leaf_bytes(list(e)) for e in polynomial_evals)
+    nodes = ctypes.create_string_buffer(32 * n)
+    leaves = ctypes.create_string_buffer(32 * k * n)
+    _lib.check(_lib.lib().sh_merkelize_packed(_lib.ctx(), data, n, k, nodes, leaves), "sh_merkelize_packed")
+    out = [nodes.raw[i:i + 32] for i in range(0, 32 * n, 32)]
+    out[0] = b""
+    w = 32 * k
+    out.extend(leaves.raw[i:i + w] for i in range(0, w * n, w))
+    return out
+
+
+def unpack_merkle_leaf(leaf, dims, num_polys):
+    """merkle_tree.py:121-147: split a packed leaf back into its 32-byte values."""
+    return [leaf[32 * i:32 * i + 32] for i in range(num_polys * dims)]

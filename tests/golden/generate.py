@@ -39,6 +39,7 @@ from starks.modp import IntegersModP  # noqa: E402
 from starks.polynomial import polynomials_over  # noqa: E402
 from starks.fft import NonBinaryFFT, fft_1d, mul_polys  # noqa: E402
 from starks.merkle_tree import merkelize, mk_branch, verify_branch, permute4, get_index_in_permuted  # noqa: E402
+from starks.merkle_tree import merkelize_polynomial_evaluations, unpack_merkle_leaf  # noqa: E402
 from starks.utils import get_power_cycle, get_pseudorandom_indices  # noqa: E402
 from starks.poly_utils import multi_interp_4, multi_inv, lagrange_interp  # noqa: E402
 from starks.compression import compress_fri, decompress_fri, compress_branches, bin_length  # noqa: E402
@@ -398,6 +399,20 @@ def gen_lde():
     dump("lde.json", out)
 
 
+def gen_packed():
+    """merkelize_polynomial_evaluations (merkle_tree.py:94-119) on seeded evaluations."""
+    out = []
+    for n, k in [(4, 1), (8, 2), (16, 3), (64, 6), (256, 3), (1024, 5)]:
+        evals = [[F(seeded(100 + c, i)) for i in range(n)] for c in range(k)]
+        t = merkelize_polynomial_evaluations(1, evals)
+        assert len(t) == 2 * n and len(t[n]) == 32 * k
+        br = mk_branch(t, n // 2 + 1)
+        out.append({"n": n, "k": k, "seed_base": 100, "root": t[1].hex(), "tree_sha": sha(b"".join(t)),
+                    "branch_index": n // 2 + 1, "branch": [b.hex() for b in br],
+                    "unpacked_leaf0": [x.hex() for x in unpack_merkle_leaf(t[n], 1, k)]})
+    dump("packed.json", out)
+
+
 def gen_compression():
     br = [[b"a" * 32, b"b" * 32, b"a" * 32], [b"b" * 32, b"c" * 32]]
     c = compress_branches(br)
@@ -410,7 +425,7 @@ if __name__ == "__main__":
     ap.add_argument("--big", action="store_true", help="also the slow cases (2^18/2^20 NTT, 2^14-step FRI)")
     ap.add_argument("--only", default="")
     a = ap.parse_args()
-    todo = a.only.split(",") if a.only else ["field", "merkle", "utils", "fold", "lde", "compression", "fri", "ntt"]
+    todo = a.only.split(",") if a.only else ["field", "merkle", "utils", "fold", "lde", "compression", "packed", "fri", "ntt"]
     for name in todo:
         fn = globals()["gen_" + name]
         if name in ("ntt", "fri"):

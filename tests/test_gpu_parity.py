@@ -405,3 +405,18 @@ def test_batched_mimc_proofs_config5_shape(sa, oracle):
     for j, flat in got:
         c = oracle.c.fft(oracle.py.mimc_trace(3 + j, steps), steps, pow(g2, 8, P), inverse=True)
         assert flat == oracle.c.fri_prove_flat(wire(c), g2, steps, 8, 40)
+
+
+def test_packed_leaf_merkle_golden(sa, oracle):
+    """merkelize_polynomial_evaluations (merkle_tree.py:94-119): multi-block BLAKE2s first level."""
+    for c in load_golden("packed.json"):
+        evals = [[sa.F(seeded(c["seed_base"] + k, i)) for i in range(c["n"])] for k in range(c["k"])]
+        t = sa.mt.merkelize_polynomial_evaluations(1, evals)
+        assert len(t) == 2 * c["n"] and t[0] == b"" and len(t[c["n"]]) == 32 * c["k"]
+        assert t[1].hex() == c["root"]
+        assert hashlib.sha256(b"".join(t)).hexdigest() == c["tree_sha"]
+        assert [b.hex() for b in sa.mt.mk_branch(t, c["branch_index"])] == c["branch"]
+        assert [x.hex() for x in sa.mt.unpack_merkle_leaf(t[c["n"]], 1, c["k"])] == c["unpacked_leaf0"]
+    n, k = 1 << 13, 7  # bigger, odd k (a block straddles the two leaves of a pair), against the oracle
+    evals = [[seeded(300 + c, i) for i in range(n)] for c in range(k)]
+    assert sa.mt.merkelize_polynomial_evaluations(1, evals) == oracle.py.merkelize_polynomial_evaluations(evals)

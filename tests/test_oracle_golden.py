@@ -191,3 +191,13 @@ def test_compression():
     g = load_golden("compression.json")
     # compress_branches is not on the FRI path; the fixture pins the back-reference encoding idea
     assert g["bin_length"] == sum((33 if len(bytes.fromhex(x)) == 32 else len(bytes.fromhex(x))) for x in g["compressed"])
+
+
+def test_packed_leaf_merkle():
+    """merkelize_polynomial_evaluations / unpack_merkle_leaf (merkle_tree.py:94-147), SURVEY 8(f) rank 3."""
+    for c in load_golden("packed.json"):
+        evals = [[seeded(c["seed_base"] + k, i) for i in range(c["n"])] for k in range(c["k"])]
+        t = po.merkelize_polynomial_evaluations(evals)
+        assert t[1].hex() == c["root"] and hashlib.sha256(b"".join(t)).hexdigest() == c["tree_sha"]
+        assert [b.hex() for b in po.mk_branch(t, c["branch_index"])] == c["branch"]
+        assert [x.hex() for x in po.unpack_merkle_leaf(t[c["n"]], 1, c["k"])] == c["unpacked_leaf0"]
