@@ -90,3 +90,35 @@ def test_host_index_sampling_matches_golden():
     from starks_amd.utils import get_pseudorandom_indices
     for c in load_golden("utils.json")["pseudorandom_indices"]:
         assert get_pseudorandom_indices(bytes.fromhex(c["entropy"]), c["modulus"], c["count"], c["exclude"]) == c["out"]
+
+
+def test_stark_helpers_restated_from_text():
+    """stark.py:106-126, 390-402 (un-importable module): structure checks on the restatement."""
+    import hashlib
+    from starks_amd.stark import get_pseudorandom_ks, compute_merkle_spot_checks
+    from starks_amd.merkle_tree import verify_branch
+    root = hashlib.blake2s(b"r").digest()
+    ks = get_pseudorandom_ks(root, 4)
+    assert ks == [int.from_bytes(hashlib.blake2s(root + s).digest(), "big") for s in (b"0x01", b"0x02", b"0x03", b"0x04")]
+    assert get_pseudorandom_ks(root, 6)[0] == int.from_bytes(hashlib.blake2s(root + b"0x00").digest(), "big")
+    assert get_pseudorandom_ks(root, 12) is None
+    # spot checks on host-built trees (heap layout of merkle_tree.py:36-56)
+    def tree(vals):
+        n = len(vals)
+        q = n // 4
+        nodes = [b""] * n + [vals[i + j * q] for i in range(q) for j in range(4)]
+        for i in range(n - 1, 0, -1):
+            nodes[i] = hashlib.blake2s(nodes[2 * i] + nodes[2 * i + 1]).digest()
+        return nodes
+    n, ext = 64, 8
+    m = tree([(i * 7 + 1).to_bytes(32, "big") for i in range(n)])
+    lt = tree([(i * 11 + 3).to_bytes(32, "big") for i in range(n)])
+    br = compute_merkle_spot_checks(m, lt, n, ext, samples=10)
+    assert len(br) == 30
+    from starks_amd.utils import get_pseudorandom_indices
+    pos = get_pseudorandom_indices(lt[1], n, 10, exclude_multiples_of=ext)
+    assert all(p % ext for p in pos)
+    for k, p in enumerate(pos):
+        assert verify_branch(m[1], p, br[3 * k], output_as_int=True) == p * 7 + 1
+        assert verify_branch(m[1], (p + ext) % n, br[3 * k + 1], output_as_int=True) == ((p + ext) % n) * 7 + 1
+        assert verify_branch(lt[1], p, br[3 * k + 2], output_as_int=True) == p * 11 + 3
