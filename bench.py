@@ -102,6 +102,30 @@ def extras(dev, quick):
                                     "algorithmic_GBps": 64.0 * n / ms / 1e6}
     dev.free(dx)
     dev.free(dt)
+    # ---- LDE: 2^16-step trace, 8x extension, 4 columns (stark.py:27-36 + 253-256) ---------------------------
+    steps, ext, cols = (1 << 12 if quick else 1 << 16), 8, 4
+    n = steps * ext
+    dtr, dout = dev.alloc(32 * steps * cols), dev.alloc(32 * n * cols)
+    dev.ck(L.sh_dev_fill_seeded(ctx, dtr, steps * cols, 11), "fill")
+    ms = dev.timed(lambda: dev.ck(L.sh_dev_lde(ctx, dtr, dout, steps, ext, cols, root_of(n).to_bytes(32, "big")), "lde"), 10)
+    out["lde_%dx2^%d_x8" % (cols, steps.bit_length() - 1)] = {"ms": round(ms, 4), "out_elements_per_s": n * cols / ms * 1e3}
+    dev.free(dtr)
+    dev.free(dout)
+    # ---- config 5 on one GPU: batches of independent 2^16-step proofs (N = 2^19 each) ---------------------------
+    steps, ext, bsz = (1 << 12 if quick else 1 << 16), 8, 32
+    n = steps * ext
+    w = root_of(n).to_bytes(32, "big")
+    plen = int(L.sh_fri_proof_len(n, steps, 40))
+    dc, dp = dev.alloc(32 * n * bsz), dev.alloc(plen * bsz)
+    dev.ck(L.sh_dev_fill_seeded(ctx, dc, n * bsz, 0xC5), "fill")
+    z = bytes(32 * (n - steps))
+    for b in range(bsz):
+        dev.ck(L.sh_dev_upload(ctx, z, ctypes.c_void_p(dc.value + 32 * (b * n + steps)), len(z)), "upload")
+    ms = dev.timed(lambda: dev.ck(L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, bsz, dp), "fri"), 3)
+    out["fri_commit_batch%d_steps_2^%d" % (bsz, steps.bit_length() - 1)] = {
+        "ms_per_batch": round(ms, 4), "proofs_per_s": bsz / ms * 1e3, "ms_per_proof": round(ms / bsz, 5)}
+    dev.free(dc)
+    dev.free(dp)
     # ---- FRI commit: 2^14-step (config 3) and 2^20-step MiMC trace, 8x extension ---------------------
     for logsteps in ([14] if quick else [14, 16, 20]):
         steps, ext = 1 << logsteps, 8

@@ -74,6 +74,7 @@ def lib():
         "sh_dev_upload": (i32, [c_p, u8p, c_p, u64]),
         "sh_dev_fill_seeded": (i32, [c_p, c_p, u64, u64]),
         "sh_dev_ntt": (i32, [c_p, c_p, c_p, u64, u32, u8p, i32]),
+        "sh_dev_lde": (i32, [c_p, c_p, c_p, u64, u32, u32, u8p]),
         "sh_dev_merkelize": (i32, [c_p, c_p, u64, u32, c_p]),
         "sh_dev_fri_fold": (i32, [c_p, c_p, c_p, u64, u32, u8p, c_p]),
         "sh_dev_fri_prove": (i32, [c_p, c_p, u64, u8p, u64, u32, u32, u32, c_p]),

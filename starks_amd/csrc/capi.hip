@@ -519,6 +519,20 @@ int sh_dev_ntt(sh_ctx* c, const void* d_in, void* d_out, uint64_t n, uint32_t ba
   SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
   return run_ntt(c, pl, reinterpret_cast<const fp*>(d_in), reinterpret_cast<fp*>(d_out), batch);
 }
+int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t ext, uint32_t cols, const uint8_t g2[32]) {
+  if (!c || !d_trace || !d_out || !g2 || cols == 0 || !is_pow2(steps) || !is_pow2(ext)) return SH_ERR_INVALID;
+  const uint64_t n = steps * ext;
+  NttPlan *inv1 = nullptr, *fwd2 = nullptr;
+  SH_TRY(plan_for(c, g2, n, false, &fwd2));
+  uint8_t g1b[32];
+  h_to_wire(h_pow(fwd2->root, ext), g1b);  // G1 = G2^ext (stark.py:217-220)
+  SH_TRY(plan_for(c, g1b, steps, true, &inv1));
+  fp* t = reinterpret_cast<fp*>(d_trace);
+  fp* x = reinterpret_cast<fp*>(d_out);
+  SH_TRY(run_ntt(c, inv1, t, t, cols));                                  // stark.py:27-36
+  HIP_TRY(c, shk_pad_copy(t, x, steps, n, cols, c->stream));             // zero padding of fft_1d (fft.py:323-324)
+  return run_ntt(c, fwd2, x, x, cols);                                   // stark.py:253-256
+}
 int sh_dev_merkelize(sh_ctx* c, const void* d_values, uint64_t n, uint32_t batch, void* d_nodes) {
   if (!c || !d_values || !d_nodes || !is_pow2(n) || n < 4 || batch == 0) return SH_ERR_INVALID;
   HIP_TRY(c, shk_merkelize(d_values, false, n, batch, reinterpret_cast<uint32_t*>(d_nodes), c->stream));

@@ -420,3 +420,21 @@ def test_packed_leaf_merkle_golden(sa, oracle):
     n, k = 1 << 13, 7  # bigger, odd k (a block straddles the two leaves of a pair), against the oracle
     evals = [[seeded(300 + c, i) for i in range(n)] for c in range(k)]
     assert sa.mt.merkelize_polynomial_evaluations(1, evals) == oracle.py.merkelize_polynomial_evaluations(evals)
+
+
+def test_device_lde_matches_host_api(sa, oracle):
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    steps, ext, cols = 1024, 8, 3
+    n = steps * ext
+    g2 = root_of(n)
+    traces = [oracle.py.mimc_trace(3 + j, steps) for j in range(cols)]
+    dtr, dout = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * steps * cols, ctypes.byref(dtr)) == 0 and L.sh_dev_alloc(ctx, 32 * n * cols, ctypes.byref(dout)) == 0
+    assert L.sh_dev_from_wire(ctx, b"".join(wire(t) for t in traces), dtr, steps * cols) == 0
+    assert L.sh_dev_lde(ctx, dtr, dout, steps, ext, cols, g2.to_bytes(32, "big")) == 0
+    host = ctypes.create_string_buffer(32 * n * cols)
+    assert L.sh_dev_to_wire(ctx, dout, host, n * cols) == 0
+    for j in range(cols):
+        assert host.raw[32 * n * j:32 * n * (j + 1)] == oracle.c.lde_bytes(wire(traces[j]), ext, g2)
+    assert L.sh_dev_free(ctx, dtr) == 0 and L.sh_dev_free(ctx, dout) == 0
