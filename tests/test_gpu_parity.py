@@ -438,3 +438,86 @@ def test_device_lde_matches_host_api(sa, oracle):
     for j in range(cols):
         assert host.raw[32 * n * j:32 * n * (j + 1)] == oracle.c.lde_bytes(wire(traces[j]), ext, g2)
     assert L.sh_dev_free(ctx, dtr) == 0 and L.sh_dev_free(ctx, dout) == 0
+
+
+# ---- randomized differential testing against the C oracle ---------------------------------------------------
+def test_randomized_ntt_differential(sa, oracle):
+    rng = random.Random(20261003)
+    for _ in range(40):
+        logn = rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+        n = 1 << logn
+        n_in = rng.choice([0, 1, n // 3, n - 1, n]) if n > 2 else n
+        batch = rng.choice([1, 1, 2, 3, 5])
+        inverse = rng.random() < 0.5
+        w = pow(root_of(n), rng.choice([1, 3, 5, n - 1]), P)  # any generator of the order-n subgroup
+        rows = [[rng.choice([0, 1, P - 1, P, 2**256 - 1, rng.randrange(2**256)]) for _ in range(n_in)] for _ in range(batch)]
+        got = sa.fft.ntt_bytes(b"".join(wire(r) for r in rows), n, w, inverse=inverse, batch=batch) if n_in else \
+            sa.fft.ntt_bytes(b"", n, w, inverse=inverse, batch=1)
+        for b, r in enumerate(rows if n_in else [[]]):
+            assert got[b * 32 * n:(b + 1) * 32 * n] == oracle.c.fft_bytes(wire(r), n, w, inverse=inverse), (logn, n_in, batch, inverse)
+
+
+def test_randomized_fri_differential(sa, oracle):
+    rng = random.Random(77)
+    for _ in range(12):
+        logn = rng.choice([6, 7, 8, 9, 10, 11, 12])
+        n = 1 << logn
+        maxdeg = n >> rng.choice([0, 1, 2, 3])
+        if maxdeg < 1:
+            maxdeg = 1
+        exclude = rng.choice([0, 0, 2, 4, 8])
+        samples = rng.choice([1, 7, 40, 41, 64])
+        batch = rng.choice([1, 2, 3])
+        w = root_of(n)
+        # every round needs a column of >= 4 values
+        nn, md, ok = n, maxdeg, True
+        while md > 16:
+            ok &= nn >= 16 and (not exclude or (nn // 4) * (exclude - 1) // exclude > 0)
+            nn //= 4
+            md //= 4
+        if not ok:
+            continue
+        n_co = rng.choice([1, maxdeg // 2 + 1, min(maxdeg, n)])
+        coeffs = [wire(rng.randrange(P) for _ in range(n_co)) for _ in range(batch)]
+        flat = sa.fri.prove_flat(b"".join(coeffs), n, w, maxdeg, exclude, samples, batch=batch)
+        plen = sa.fri.proof_len(n, maxdeg, samples)
+        for b in range(batch):
+            want = oracle.c.fri_prove_flat(coeffs[b], w, maxdeg, exclude, samples, n=n)
+            assert flat[b * plen:(b + 1) * plen] == want, (logn, maxdeg, exclude, samples, batch, n_co)
+
+
+def test_two_process_sharded_proving(sa, oracle, tmp_path):
+    """The N > 1 path with real GPU work: two processes (gloo rendezvous, both on this box's GPU) each prove their
+    shard of 6 MiMC traces and all_gather the digests; every rank must end with the oracle's digests in unit order."""
+    import subprocess, sys, textwrap
+    from conftest import ROOT
+    script = tmp_path / "worker.py"
+    script.write_text(textwrap.dedent("""
+        import hashlib, os, sys
+        sys.path.insert(0, %r)
+        os.environ["STARKHIP_DEVICE"] = "0"
+        import torch.distributed as dist
+        from starks_amd import batch
+        dist.init_process_group(backend="gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        mine = batch.shard(6, rank, world)
+        proofs = batch.prove_mimc_batch(mine, 128, chunk=2)
+        digs = batch.gather_digests([batch.digest(p) for _, p in proofs], 6, rank, world, dist, "cpu")
+        print("RANK", rank, "DIGESTS", ",".join(d.hex() for d in digs), flush=True)
+        dist.destroy_process_group()
+    """ % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    steps = 128
+    g2 = root_of(steps * 8)
+    want = []
+    for j in range(6):
+        c = oracle.c.fft(oracle.py.mimc_trace(3 + j, steps), steps, pow(g2, 8, P), inverse=True)
+        want.append(hashlib.sha256(oracle.c.fri_prove_flat(wire(c), g2, steps, 8, 40)).hexdigest())
+    lines = [l for l in out.stdout.splitlines() if l.startswith("RANK")]
+    assert len(lines) == 2
+    for l in lines:
+        assert l.split("DIGESTS ")[1].split(",") == want
