@@ -74,6 +74,10 @@ struct sh_ctx {
   enum { WS_WIRE = 0, WS_X, WS_Y, WS_NTT, WS_TREE_A, WS_TREE_B, WS_COL_A, WS_COL_B, WS_MISC, WS_PROOF, WS_COUNT };
   void* ws[WS_COUNT] = {};
   size_t ws_cap[WS_COUNT] = {};
+  // pinned staging for host <-> device copies of caller (pageable) buffers: two slots, double buffered
+  uint8_t* pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
+  bool pin_busy[2] = {false, false};
 };
 
 namespace {
@@ -109,6 +113,78 @@ int ws_get(sh_ctx* c, int slot, size_t bytes, void** out) {
     c->ws_cap[slot] = cap;
   }
   *out = c->ws[slot];
+  return SH_OK;
+}
+
+
+constexpr size_t PIN_CHUNK = (size_t)8 << 20;
+
+int pin_init(sh_ctx* c) {
+  if (c->pin[0]) return SH_OK;
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->pin[i]), PIN_CHUNK, hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+  }
+  return SH_OK;
+}
+int pin_wait(sh_ctx* c, int slot) {
+  if (c->pin_busy[slot]) {
+    HIP_TRY(c, hipEventSynchronize(c->pin_ev[slot]));
+    c->pin_busy[slot] = false;
+  }
+  return SH_OK;
+}
+// host (pageable) -> device through the pinned slots: the host memcpy of chunk i+1 overlaps the DMA of chunk i.
+// Returns once `h` has been consumed; the device copy completes in stream order.
+int h2d(sh_ctx* c, void* d, const void* h, size_t bytes) {
+  if (bytes == 0) return SH_OK;
+  if (bytes < ((size_t)64 << 10)) {
+    HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return SH_OK;
+  }
+  SH_TRY(pin_init(c));
+  size_t off = 0;
+  for (int i = 0; off < bytes; ++i) {
+    const int slot = i & 1;
+    const size_t len = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+    SH_TRY(pin_wait(c, slot));
+    memcpy(c->pin[slot], static_cast<const uint8_t*>(h) + off, len);
+    HIP_TRY(c, hipMemcpyAsync(static_cast<uint8_t*>(d) + off, c->pin[slot], len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->pin_ev[slot], c->stream));
+    c->pin_busy[slot] = true;
+    off += len;
+  }
+  return SH_OK;
+}
+// device -> host (pageable); blocks until `h` is complete.
+int d2h(sh_ctx* c, void* h, const void* d, size_t bytes) {
+  if (bytes == 0) return SH_OK;
+  if (bytes < ((size_t)64 << 10)) {
+    HIP_TRY(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SH_OK;
+  }
+  SH_TRY(pin_init(c));
+  SH_TRY(pin_wait(c, 0));
+  SH_TRY(pin_wait(c, 1));
+  size_t off = 0, prev_off = 0, prev_len = 0;
+  int prev_slot = -1;
+  for (int i = 0; off < bytes; ++i) {
+    const int slot = i & 1;
+    const size_t len = bytes - off < PIN_CHUNK ? bytes - off : PIN_CHUNK;
+    HIP_TRY(c, hipMemcpyAsync(c->pin[slot], static_cast<const uint8_t*>(d) + off, len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->pin_ev[slot], c->stream));
+    if (prev_slot >= 0) {  // drain the previous chunk while this one is in flight
+      HIP_TRY(c, hipEventSynchronize(c->pin_ev[prev_slot]));
+      memcpy(static_cast<uint8_t*>(h) + prev_off, c->pin[prev_slot], prev_len);
+    }
+    prev_slot = slot;
+    prev_off = off;
+    prev_len = len;
+    off += len;
+  }
+  HIP_TRY(c, hipEventSynchronize(c->pin_ev[prev_slot]));
+  memcpy(static_cast<uint8_t*>(h) + prev_off, c->pin[prev_slot], prev_len);
   return SH_OK;
 }
 
@@ -438,6 +514,10 @@ void sh_ctx_destroy(sh_ctx* c) {
   }
   for (int i = 0; i < sh_ctx::WS_COUNT; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
+  for (int i = 0; i < 2; ++i) {
+    if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+    if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
+  }
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -479,21 +559,19 @@ int sh_dev_free(sh_ctx* c, void* dptr) {
 }
 int sh_dev_upload(sh_ctx* c, const void* host_src, void* d_dst, uint64_t bytes) {
   if (!c || (!host_src && bytes) || (!d_dst && bytes)) return SH_ERR_INVALID;
-  HIP_TRY(c, hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+  SH_TRY(h2d(c, d_dst, host_src, bytes));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SH_OK;
 }
 int sh_dev_download(sh_ctx* c, const void* d_src, void* host_dst, uint64_t bytes) {
   if (!c || (!host_dst && bytes) || (!d_src && bytes)) return SH_ERR_INVALID;
-  HIP_TRY(c, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SH_OK;
+  return d2h(c, host_dst, d_src, bytes);
 }
 int sh_dev_from_wire(sh_ctx* c, const uint8_t* host_wire, void* d_limbs, uint64_t n) {
   if (!c || (n && (!host_wire || !d_limbs))) return SH_ERR_INVALID;
   void* w = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, n * 32, &w));
-  HIP_TRY(c, hipMemcpyAsync(w, host_wire, n * 32, hipMemcpyHostToDevice, c->stream));
+  SH_TRY(h2d(c, w, host_wire, n * 32));
   HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<const uint8_t*>(w), reinterpret_cast<fp*>(d_limbs), n, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SH_OK;
@@ -503,9 +581,7 @@ int sh_dev_to_wire(sh_ctx* c, const void* d_limbs, uint8_t* host_wire, uint64_t 
   void* w = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, n * 32, &w));
   HIP_TRY(c, shk_limb_to_wire(reinterpret_cast<const fp*>(d_limbs), reinterpret_cast<uint8_t*>(w), n, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(host_wire, w, n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SH_OK;
+  return d2h(c, host_wire, w, n * 32);
 }
 int sh_dev_fill_seeded(sh_ctx* c, void* d_limbs, uint64_t n, uint64_t seed) {
   if (!c || (n && !d_limbs)) return SH_ERR_INVALID;
@@ -573,12 +649,12 @@ static int upload_padded(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint64_t n
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)batch * (n_in > n ? n_in : n) * 32, &w));
   SH_TRY(ws_get(c, slot, (size_t)batch * n * sizeof(fp), &x));
   if (n_in == n) {
-    HIP_TRY(c, hipMemcpyAsync(w, in, (size_t)batch * n * 32, hipMemcpyHostToDevice, c->stream));
+    SH_TRY(h2d(c, w, in, (size_t)batch * n * 32));
     HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<uint8_t*>(w), reinterpret_cast<fp*>(x), (uint64_t)batch * n, c->stream));
   } else {
     SH_TRY(ws_get(c, sh_ctx::WS_MISC, (size_t)batch * (n_in ? n_in : 1) * sizeof(fp), &y));
     if (n_in) {
-      HIP_TRY(c, hipMemcpyAsync(w, in, (size_t)batch * n_in * 32, hipMemcpyHostToDevice, c->stream));
+      SH_TRY(h2d(c, w, in, (size_t)batch * n_in * 32));
       HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<uint8_t*>(w), reinterpret_cast<fp*>(y), (uint64_t)batch * n_in, c->stream));
     }
     HIP_TRY(c, shk_pad_copy(reinterpret_cast<fp*>(y), reinterpret_cast<fp*>(x), n_in, n, batch, c->stream));  // fft.py:323-324
@@ -590,9 +666,7 @@ static int download_wire(sh_ctx* c, const fp* d, uint8_t* out, uint64_t count) {
   void* w = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)count * 32, &w));
   HIP_TRY(c, shk_limb_to_wire(d, reinterpret_cast<uint8_t*>(w), count, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(out, w, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SH_OK;
+  return d2h(c, out, w, (size_t)count * 32);
 }
 
 int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t n, uint32_t batch,
@@ -665,11 +739,9 @@ int sh_merkelize(sh_ctx* c, const uint8_t* leaves, uint64_t n, uint8_t* nodes) {
   void *w = nullptr, *t = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)n * 32, &w));
   SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)2 * n * 32, &t));
-  HIP_TRY(c, hipMemcpyAsync(w, leaves, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+  SH_TRY(h2d(c, w, leaves, (size_t)n * 32));
   HIP_TRY(c, shk_merkelize(w, true, n, 1, reinterpret_cast<uint32_t*>(t), c->stream));
-  HIP_TRY(c, hipMemcpyAsync(nodes, t, (size_t)2 * n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SH_OK;
+  return d2h(c, nodes, t, (size_t)2 * n * 32);
 }
 
 int sh_merkelize_packed(sh_ctx* c, const uint8_t* evals, uint64_t n, uint32_t k, uint8_t* nodes, uint8_t* leaves) {
@@ -680,13 +752,11 @@ int sh_merkelize_packed(sh_ctx* c, const uint8_t* evals, uint64_t n, uint32_t k,
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, ebytes, &w));
   SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)2 * n * 32, &t));
   SH_TRY(ws_get(c, sh_ctx::WS_X, ebytes, &l));
-  HIP_TRY(c, hipMemcpyAsync(w, evals, ebytes, hipMemcpyHostToDevice, c->stream));
+  SH_TRY(h2d(c, w, evals, ebytes));
   HIP_TRY(c, shk_merkelize_packed(reinterpret_cast<const uint8_t*>(w), n, k, reinterpret_cast<uint8_t*>(l),
                                   reinterpret_cast<uint32_t*>(t), c->stream));
-  HIP_TRY(c, hipMemcpyAsync(nodes, t, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(leaves, l, ebytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SH_OK;
+  SH_TRY(d2h(c, nodes, t, (size_t)n * 32));
+  return d2h(c, leaves, l, ebytes);
 }
 
 int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root[32], const uint8_t special_x[32],
@@ -735,9 +805,7 @@ int sh_fri_prove(sh_ctx* c, const uint8_t* coeffs, uint64_t n_coeffs, uint64_t n
   void* dp = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_PROOF, (size_t)stride * batch, &dp));
   SH_TRY(run_fri(c, x, n, root, maxdeg_plus_1, exclude, samples, batch, reinterpret_cast<uint8_t*>(dp)));
-  HIP_TRY(c, hipMemcpyAsync(proof, dp, (size_t)stride * batch, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return SH_OK;
+  return d2h(c, proof, dp, (size_t)stride * batch);
 }
 
 }  // extern "C"
