@@ -89,17 +89,25 @@ FP_HD fp fp_add(const fp& a, const fp& b) {
 }
 
 // (a - b) mod p, lazily reduced.  modp.py:47-49.
+// A borrow means the 256-bit difference r stands for r - 2^256 == r - c.  It is folded as r + p (mod 2^256) rather than
+// r - c: every limb of p is non-zero, so the chain is eight plain v_addc (hipcc lowers "x - 0 - borrow" to
+// v_cndmask + v_sub_co, two instructions per zero limb of c).  r + p wraps exactly when r >= c; if it does not, the
+// value held is r + p == r (mod p) and c is subtracted once more (limbs 0..1 only: r + p = 2^256 - (c - r)).
 FP_HD fp fp_sub(const fp& a, const fp& b) {
   fp r;
   uint32_t bw = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = fp_subb(a.v[i], b.v[i], bw, &bw);
-  uint32_t bw2 = fp_sub_c_masked(r, bw);  // -2^256 == -c
-  // second borrow: r = 2^256 - d with d < 2^41 (limbs 2..7 all ones); subtracting c again only
-  // touches limbs 0..1 and cannot borrow out of them
-  uint32_t mask = 0u - bw2, b3;
-  r.v[0] = fp_subb(r.v[0], FP_C0 & mask, 0, &b3);
-  r.v[1] = fp_subb(r.v[1], FP_C1 & mask, b3, &b3);
+  const uint32_t m = 0u - bw;
+  uint32_t cy;
+  r.v[0] = fp_addc(r.v[0], FP_P0 & m, 0, &cy);
+  r.v[1] = fp_addc(r.v[1], FP_P1 & m, cy, &cy);
+#pragma unroll
+  for (int i = 2; i < 8; ++i) r.v[i] = fp_addc(r.v[i], m, cy, &cy);
+  const uint32_t m2 = m & (cy - 1u);  // borrowed and r + p did not wrap
+  uint32_t b3;
+  r.v[0] = fp_subb(r.v[0], FP_C0 & m2, 0, &b3);
+  r.v[1] = fp_subb(r.v[1], FP_C1 & m2, b3, &b3);
   return r;
 }
 
@@ -173,21 +181,20 @@ FP_HD fp fp_reduce_wide(const uint32_t t[16]) {
     R[i] = fp_subb(s, hi, b1, &b1);
   }
   // (c1 and b1 cancel at the top: R < 2^298 fits in 10 limbs, so final c1 == b1.)
-  // second fold: h2 = R[8] + R[9]*2^32 (< 2^42);  r = R[0..7] + (h2*351 << 32) - h2
+  // second fold: h2 = R[8] + R[9]*2^32 (< 2^42);  r = R[0..7] + h2*c,  h2*c = (h2*351 << 32) - h2 =: D (3 limbs, >= 0).
+  // D is formed first so that the long chain is an addition (adding zero limbs with carry is one v_addc each;
+  // subtracting zero limbs with borrow is not, see fp_sub).
   uint64_t h2 = (uint64_t)R[8] | ((uint64_t)R[9] << 32);
   uint64_t B = h2 * 351u;  // < 2^51
+  uint32_t D[3], bd = 0;
+  D[0] = fp_subb(0u, R[8], 0, &bd);
+  D[1] = fp_subb((uint32_t)B, R[9], bd, &bd);
+  D[2] = (uint32_t)(B >> 32) - bd;
   fp r;
-  uint32_t c2 = 0, b2 = 0;
+  uint32_t c2 = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint32_t as = i == 1 ? (uint32_t)B : (i == 2 ? (uint32_t)(B >> 32) : 0u);
-    uint32_t hs = i == 0 ? R[8] : (i == 1 ? R[9] : 0u);
-    uint32_t s = fp_addc(R[i], as, c2, &c2);
-    r.v[i] = fp_subb(s, hs, b2, &b2);
-  }
-  // net carry out of limb 7 is c2 - b2 in {0, 1} (the value is non-negative)
-  uint32_t over = c2 - b2;
-  fp_add_c_masked_low(r, over);  // after a wrap r < 2^84: three limbs suffice
+  for (int i = 0; i < 8; ++i) r.v[i] = fp_addc(R[i], i < 3 ? D[i] : 0u, c2, &c2);
+  fp_add_c_masked_low(r, c2);  // after a wrap r < 2^84: three limbs suffice
   return r;
 }
 
