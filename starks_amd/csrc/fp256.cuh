@@ -18,6 +18,14 @@
 
 #define FP_HD __host__ __device__ __forceinline__
 
+// "does any lane of the wave see this rare condition?" -- a wave-uniform branch (s_cbranch on the ballot), so the
+// common path skips the rare carry-propagation chains entirely.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FP_ANY(x) (__builtin_amdgcn_ballot_w64((x) != 0) != 0)
+#else
+#define FP_ANY(x) ((x) != 0)
+#endif
+
 struct fp {
   uint32_t v[8];
 };
@@ -78,36 +86,47 @@ FP_HD uint32_t fp_sub_c_masked(fp& a, uint32_t m) {
 }
 
 // (a + b) mod p, lazily reduced.  modp.py:43-45.
+// A carry out of limb 7 is folded as + c (2^256 == c).  c has two limbs, so the fold touches limbs 0..1; a carry
+// out of limb 1 needs limb 1 >= 2^32 - 351 (probability ~1e-7 per lane): the propagation through limbs 2..7 and
+// the possible second wrap live behind a wave-uniform branch that is almost never taken.
 FP_HD fp fp_add(const fp& a, const fp& b) {
   fp r;
   uint32_t cy = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = fp_addc(a.v[i], b.v[i], cy, &cy);
-  uint32_t cy2 = fp_add_c_masked(r, cy);  // 2^256 == c
-  fp_add_c_masked_low(r, cy2);            // second wrap leaves r < 2^42, cannot wrap again
+  const uint32_t m = 0u - cy;
+  uint32_t c1;
+  r.v[0] = fp_addc(r.v[0], FP_C0 & m, 0, &c1);
+  r.v[1] = fp_addc(r.v[1], FP_C1 & m, c1, &c1);
+  if (FP_ANY(c1)) {
+#pragma unroll
+    for (int i = 2; i < 8; ++i) r.v[i] = fp_addc(r.v[i], 0, c1, &c1);
+    fp_add_c_masked_low(r, c1);  // second wrap leaves r < 2^42, cannot wrap again
+  }
   return r;
 }
 
 // (a - b) mod p, lazily reduced.  modp.py:47-49.
-// A borrow means the 256-bit difference r stands for r - 2^256 == r - c.  It is folded as r + p (mod 2^256) rather than
-// r - c: every limb of p is non-zero, so the chain is eight plain v_addc (hipcc lowers "x - 0 - borrow" to
-// v_cndmask + v_sub_co, two instructions per zero limb of c).  r + p wraps exactly when r >= c; if it does not, the
-// value held is r + p == r (mod p) and c is subtracted once more (limbs 0..1 only: r + p = 2^256 - (c - r)).
+// A borrow means the 256-bit difference stands for r - 2^256 == r - c: subtract c from limbs 0..1; a borrow out of
+// limb 1 (limb 1 < 351, ~1e-7 per lane) is propagated behind a wave-uniform branch, where a second borrow (r was < c)
+// means the value now is 2^256 - d with d < 2^41 and c is subtracted once more from limbs 0..1.
 FP_HD fp fp_sub(const fp& a, const fp& b) {
   fp r;
   uint32_t bw = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = fp_subb(a.v[i], b.v[i], bw, &bw);
   const uint32_t m = 0u - bw;
-  uint32_t cy;
-  r.v[0] = fp_addc(r.v[0], FP_P0 & m, 0, &cy);
-  r.v[1] = fp_addc(r.v[1], FP_P1 & m, cy, &cy);
+  uint32_t b1;
+  r.v[0] = fp_subb(r.v[0], FP_C0 & m, 0, &b1);
+  r.v[1] = fp_subb(r.v[1], FP_C1 & m, b1, &b1);
+  if (FP_ANY(b1)) {
 #pragma unroll
-  for (int i = 2; i < 8; ++i) r.v[i] = fp_addc(r.v[i], m, cy, &cy);
-  const uint32_t m2 = m & (cy - 1u);  // borrowed and r + p did not wrap
-  uint32_t b3;
-  r.v[0] = fp_subb(r.v[0], FP_C0 & m2, 0, &b3);
-  r.v[1] = fp_subb(r.v[1], FP_C1 & m2, b3, &b3);
+    for (int i = 2; i < 8; ++i) r.v[i] = fp_subb(r.v[i], 0, b1, &b1);
+    const uint32_t m2 = 0u - b1;
+    uint32_t b3;
+    r.v[0] = fp_subb(r.v[0], FP_C0 & m2, 0, &b3);
+    r.v[1] = fp_subb(r.v[1], FP_C1 & m2, b3, &b3);
+  }
   return r;
 }
 
@@ -193,8 +212,14 @@ FP_HD fp fp_reduce_wide(const uint32_t t[16]) {
   fp r;
   uint32_t c2 = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = fp_addc(R[i], i < 3 ? D[i] : 0u, c2, &c2);
-  fp_add_c_masked_low(r, c2);  // after a wrap r < 2^84: three limbs suffice
+  for (int i = 0; i < 3; ++i) r.v[i] = fp_addc(R[i], D[i], c2, &c2);
+#pragma unroll
+  for (int i = 3; i < 8; ++i) r.v[i] = R[i];
+  if (FP_ANY(c2)) {  // carry out of limb 2: ~1e-4 per lane (D[2] < 2^19)
+#pragma unroll
+    for (int i = 3; i < 8; ++i) r.v[i] = fp_addc(r.v[i], 0u, c2, &c2);
+    fp_add_c_masked_low(r, c2);  // after a wrap r < 2^84: three limbs suffice
+  }
   return r;
 }
 

@@ -519,3 +519,31 @@ def test_two_process_sharded_proving(sa, oracle, tmp_path):
         want.append(hashlib.sha256(oracle.c.fri_prove_flat(wire(c), g2, steps, 8, 40)).hexdigest())
     for rank in (0, 1):
         assert (tmp_path / ("rank%d.txt" % rank)).read_text().split(",") == want
+
+
+def test_rare_carry_branches(sa):
+    """fp_add / fp_sub / the reduction keep their rare carry propagation behind wave-uniform branches
+    (fp256.cuh); these inputs force every one of them, alone in a wave and mixed with ordinary lanes."""
+    import ctypes
+    M = 1 << 256
+    c = M - P
+    H = (2 * M - 1) // c
+    pairs = [(M - 1, M - (1 << 32) + 6),          # add: carry, fold carry leaves limb 1, second wrap
+             (0, M - 5),                          # sub: borrow, fold borrow leaves limb 1, second borrow
+             ((7 << 64) + 2, M - 1),              # sub: borrow leaves limb 1, no second borrow
+             (M - 1, M - 1), (P, P - 1), (5, 7)]
+    rng = random.Random(9)
+    filler = [(rng.randrange(M), rng.randrange(M)) for _ in range(70)]
+    for batch_pairs in ([p] for p in pairs):
+        a, b = batch_pairs[0]
+        out = unwire(sa.fft.ntt_bytes(wire([a, b]), 2, P - 1))   # n = 2: (a + b, a - b)
+        assert out == [(a + b) % P, (a - b) % P]
+    mixed = filler[:30] + pairs + filler[30:]
+    got = unwire(sa.fft.ntt_bytes(b"".join(wire([a, b]) for a, b in mixed), 2, P - 1, batch=len(mixed)))
+    assert got == [v for a, b in mixed for v in ((a + b) % P, (a - b) % P)]
+    # products through mul_polys with n = 1 (NTT of length 1 is the identity): x * y mod p
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    for x, y in [(2 * H, 1 << 255), (M - 1, M - 1), (P - 1, P - 1), (H, 1 << 255), (2 * H + 1, (1 << 255) + 12345)]:
+        out = ctypes.create_string_buffer(32)
+        assert L.sh_mul_polys(ctx, x.to_bytes(32, "big"), 1, y.to_bytes(32, "big"), 1, out, 1, (1).to_bytes(32, "big")) == 0
+        assert int.from_bytes(out.raw, "big") == x * y % P

@@ -364,6 +364,19 @@ int main() {
   setall(hin[8], 0xffffffffu); hin[8].v[1] = 0xfffffea1u; hin[8].v[0] = 1; setall(hin[9], 0xffffffffu);  // p, 2^256-1
   setall(hin[10], 0); setall(hin[11], 0); hin[11].v[0] = 1;                                            // 0 - 1
   setall(hin[12], 0); hin[12].v[0] = 5; setall(hin[13], 0xffffffffu); hin[13].v[0] = 0xfffffff0u;   // small - huge
+  // rare wave-uniform branches of fp_add / fp_sub / fp_reduce_wide (vectors crafted with a Python model)
+  // add: a = 2^256-1, b = 2^256-2^32+6 -> carry; the fold's carry leaves limb 1; second wrap
+  setall(hin[14], 0xffffffffu);
+  setall(hin[15], 0xffffffffu); hin[15].v[0] = 6;
+  // sub: 0 - (2^256-5): borrow, the fold's borrow leaves limb 1, second borrow
+  setall(hin[16], 0); setall(hin[17], 0xffffffffu); hin[17].v[0] = 0xfffffffbu;
+  // sub: wrapped difference 7*2^64+3: borrow leaves limb 1, no second borrow (a = r - 1, b = 2^256 - 1)
+  setall(hin[18], 0); hin[18].v[0] = 2; hin[18].v[2] = 7; setall(hin[19], 0xffffffffu);
+  // mul: x = 2*floor((2^257-1)/c), y = 2^255: the second fold carries out of limb 2 and wraps once more
+  setall(hin[20], 0);
+  hin[20].v[0] = 0x87417e26u; hin[20].v[1] = 0x72cbf66fu; hin[20].v[2] = 0x65a6e2eau; hin[20].v[3] = 0x5fd11f73u;
+  hin[20].v[4] = 0x5fba1f38u; hin[20].v[5] = 0x4030ce4bu; hin[20].v[6] = 0x02ead958u;
+  setall(hin[21], 0); hin[21].v[7] = 0x80000000u;
   fp *din, *dres;
   CK(hipMalloc(&din, sizeof(fp) * nthreads * 2));
   CK(hipMalloc(&dres, sizeof(fp) * nthreads * 4));
