@@ -2,16 +2,16 @@
 """profiles/<round>_traffic.json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of `bench.py` (tools/prof_traffic.sh).
 HBM bytes per launch of the dominant kernel = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE
 reports half of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact."""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
 def per_kernel(root, counter):
-    f = glob.glob(root + "/*/*_counter_collection.csv")[0]
+    f = max(glob.glob(root + "/*/*_counter_collection.csv"), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return acc
 def durations(root):
-    f = glob.glob(root + "/*/*_kernel_stats.csv")[0]
+    f = max(glob.glob(root + "/*/*_kernel_stats.csv"), key=os.path.getmtime)
     return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(f))}
 if __name__ == "__main__":
     fdir, wdir, sdir, out = sys.argv[1:5]

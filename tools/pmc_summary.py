@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection.csv files: per kernel name, mean counter values per dispatch."""
-import csv, glob, sys, collections
+import csv, glob, os, sys, collections
 def summarize(path):
     rows = list(csv.DictReader(open(path)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -15,8 +15,8 @@ def durations(path):
 if __name__ == "__main__":
     for root in sys.argv[1:]:
         print("==", root)
-        cc = glob.glob(root + "/*/*_counter_collection.csv")[0]
-        kt = glob.glob(root + "/*/*_kernel_trace.csv")[0]
+        cc = max(glob.glob(root + "/*/*_counter_collection.csv"), key=os.path.getmtime)
+        kt = max(glob.glob(root + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
         agg, dur = summarize(cc), durations(kt)
         for k, cs in agg.items():
             if "ntt_pass" not in k and "merkle" not in k and "fold" not in k:
