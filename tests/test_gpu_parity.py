@@ -547,3 +547,23 @@ def test_rare_carry_branches(sa):
         out = ctypes.create_string_buffer(32)
         assert L.sh_mul_polys(ctx, x.to_bytes(32, "big"), 1, y.to_bytes(32, "big"), 1, out, 1, (1).to_bytes(32, "big")) == 0
         assert int.from_bytes(out.raw, "big") == x * y % P
+
+
+def test_degenerate_inputs(sa, oracle):
+    """Zero / constant / maximal inputs: identical leaves, zero columns, all-(p-1) vectors."""
+    n = 1 << 10
+    w = root_of(n)
+    for vec in ([0] * n, [P - 1] * n, [1] + [0] * (n - 1), [2**256 - 1] * n):
+        data = wire(vec)
+        assert sa.fft.ntt_bytes(data, n, w) == oracle.c.fft_bytes(data, n, w)
+        assert sa.fft.ntt_bytes(data, n, w, inverse=True) == oracle.c.fft_bytes(data, n, w, inverse=True)
+    for leaves in (bytes(32 * 64), b"\xff" * (32 * 64), wire([7] * 64)):
+        assert sa.mt.merkelize_bytes(leaves) == oracle.c.merkelize_bytes(leaves)
+    # FRI of the zero polynomial, a constant, and x^(maxdeg-1): every column is highly structured
+    for coeffs in ([], [5], [0] * 255 + [1]):
+        flat = sa.fri.prove_flat(wire(coeffs), n, w, 256, 0, 40)
+        assert flat == oracle.c.fri_prove_flat(wire(coeffs), w, 256, 0, 40, n=n)
+    # reference-level API with a Poly that strips to nothing (polynomial.py:58)
+    from starks_amd.polynomial import polynomials_over
+    zero = polynomials_over(sa.F).factory([0, 0, 0])
+    assert zero.coefficients == [] and [int(v) for v in sa.fft.NonBinaryFFT(sa.F, sa.F(root_of(16))).fft(zero)] == [0] * 16
