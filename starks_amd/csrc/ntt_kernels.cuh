@@ -19,9 +19,22 @@
 
 // LDS image of a tile: 32-byte elements, 8 to a 256-byte bank row; the slot inside the row is XOR-ed with
 // the higher index bits so that any power-of-two stride between lanes spreads over all 8 slots.
-__device__ __forceinline__ uint32_t lds_slot(uint32_t e) {
+__host__ __device__ constexpr uint32_t lds_slot(uint32_t e) {
   uint32_t s = (e ^ (e >> 3) ^ (e >> 6) ^ (e >> 9)) & 7u;
   return (((e >> 3) << 3) | s) * 2u;  // in uint4 units
+}
+// lds_slot is linear over GF(2) (shifts, XOR, disjoint masks), so lds_slot(e ^ d) == lds_slot(e) ^ lds_slot(d): a
+// thread computes the slot of its first element once and reaches the other three with one XOR by a constant.
+__device__ __forceinline__ void lds_put_at(uint4* lds, uint32_t o, const fp& r) {
+  lds[o] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  lds[o + 1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+__device__ __forceinline__ fp lds_get_at(const uint4* lds, uint32_t o) {
+  uint4 a = lds[o], b = lds[o + 1];
+  fp r;
+  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+  return r;
 }
 __device__ __forceinline__ void lds_put(uint4* lds, uint32_t e, const fp& r) {
   uint32_t o = lds_slot(e);
@@ -115,7 +128,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
         th.x[h] = fp_zero();
       }
     } else {
-      th.x[h] = lds_get(lds, (i << LOG_T) | th.t);
+      th.x[h] = lds_get_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)));
     }
   }
 
@@ -152,8 +165,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     if (g > 0) __syncthreads();  // everyone has finished reading the previous image
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-      const uint32_t i = th.ibase | ((uint32_t)h << beta);
-      lds_put(lds, (i << LOG_T) | th.t, th.x[h]);
+      lds_put_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)), th.x[h]);
     }
     __syncthreads();
   }
