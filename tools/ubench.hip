@@ -9,6 +9,7 @@
 #include <vector>
 #include "fp256.cuh"
 #include "fp29.cuh"
+#include "blake2s.cuh"
 
 #define CK(x)                                                                      \
   do {                                                                             \
@@ -207,6 +208,20 @@ __global__ void k_f29check(const fp* in, fp* out, int n) {
   out[gid * 4 + 2] = fp_canon(f29_to_fp(f29_sub(xa, m)));                    // a - a*b
   fp29 d = f29_sub(f29_sub(f29_sub(xa, m), m), m);                           // a - 3ab (lazy, negative limbs)
   out[gid * 4 + 3] = fp_canon(f29_to_fp(f29_mul(f29_normalize(d), wb)));     // (a - 3ab) * b
+}
+
+// BLAKE2s throughput: a chain of 64 pair-hashes per lane
+__global__ void __launch_bounds__(256) k_blake(const fp* in, fp* out) {
+  int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  fp a = in[gid * 2], b = in[gid * 2 + 1];
+  b2digest d;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d.h[k] = a.v[k];
+  for (int i = 0; i < 64; ++i) d = b2_hash_pair(d.h, b.v);
+  fp r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = d.h[k];
+  out[gid] = r;
 }
 
 __global__ void k_fpcheck(const fp* in, fp* out, int n) {
@@ -438,6 +453,8 @@ int main() {
     double s2 = time_kernel([&] { hipLaunchKernelGGL(k_fpmul<2>, dim3(bl), dim3(threads), 0, 0, din, dres); });
     double s3 = time_kernel([&] { hipLaunchKernelGGL(k_fpbfly, dim3(bl), dim3(threads), 0, 0, din, dres); });
     double s4 = time_kernel([&] { hipLaunchKernelGGL(k_fpaddsub, dim3(bl), dim3(threads), 0, 0, din, dres); });
+    double s7 = time_kernel([&] { hipLaunchKernelGGL(k_blake, dim3(bl), dim3(threads), 0, 0, din, dres); });
+    printf("blocks/CU=%d  BLAKE2s pair hashes: %7.2f G/s\n", wpb, (double)nt * 64 / s7 * 1e-9);
     double s5 = time_kernel([&] { hipLaunchKernelGGL(k_f29mul, dim3(bl), dim3(threads), 0, 0, din, dres); });
     double s6 = time_kernel([&] { hipLaunchKernelGGL(k_f29bfly, dim3(bl), dim3(threads), 0, 0, din, dres); });
     printf("blocks/CU=%d  modmul x1: %7.2f G/s   x2: %7.2f G/s   butterfly: %7.2f G/s   add+sub pair: %7.2f G/s | f29 mul: %7.2f G/s  f29 DIT butterfly: %7.2f G/s\n", wpb,
