@@ -201,3 +201,46 @@ def test_packed_leaf_merkle():
         assert t[1].hex() == c["root"] and hashlib.sha256(b"".join(t)).hexdigest() == c["tree_sha"]
         assert [b.hex() for b in po.mk_branch(t, c["branch_index"])] == c["branch"]
         assert [x.hex() for x in po.unpack_merkle_leaf(t[c["n"]], 1, c["k"])] == c["unpacked_leaf0"]
+
+
+def _stark_case(c):
+    sp = [{tuple(k): v for k, v in d} for d in c["step_polys"]]
+    return sp, po.get_computational_trace(c["inputs"], c["steps"], sp)
+
+
+@pytest.mark.parametrize("c", load_golden("stark.json"), ids=lambda c: c["name"])
+def test_stark_proofs(c):
+    """STARK.mk_proof / verify_proof of the LIVE reference (stark.py:233-388; cases of test_stark.py:215-350)."""
+    sp, w = _stark_case(c)
+    assert [[v for v in col] for col in w] == [[h2i(x) for x in col] for col in c["witness"]]
+    _, tps, ds, bs = po.stark_polys(w, c["inputs"], sp, c["steps"], c["ext"])
+    unhex = lambda L: [[h2i(x) for x in q] for q in L]
+    assert tps == unhex(c["trace_polys"])
+    assert ds == unhex(c["remainder_polys"])
+    assert bs == unhex(c["boundary_polys"])
+    proof = po.mk_stark_proof(w, c["inputs"], sp, c["steps"], c["ext"])
+    assert proof[0].hex() == c["m_root"] and proof[1].hex() == c["l_root"]
+    assert len(proof[2]) == c["n_branches"] and [len(b) for b in proof[2][:3]] == c["branch_lens"]
+    assert [b.hex() for b in proof[2][0]] == c["branch0"]
+    assert len(proof[3]) == c["fri_rounds"]
+    assert max(po.mv_degree(q) for q in sp) == c["degree"]
+    flat = po.stark_flat(proof)
+    assert len(flat) == c["flat_len"] and hashlib.sha256(flat).hexdigest() == c["flat_sha"]
+    path = os.path.join(GOLDEN, "stark_%s.flat.bin" % c["name"])
+    if os.path.exists(path):
+        assert flat == open(path, "rb").read()
+    assert po.verify_stark_proof(proof, [col[-1] for col in w], c["inputs"], sp, c["steps"], c["ext"])
+
+
+def test_stark_verifier_rejects():
+    c = load_golden("stark.json")[0]
+    sp, w = _stark_case(c)
+    proof = po.mk_stark_proof(w, c["inputs"], sp, c["steps"], c["ext"])
+    outs = [col[-1] for col in w]
+    with pytest.raises(AssertionError):  # wrong claimed output: the boundary check fails (stark.py:373)
+        po.verify_stark_proof(proof, [outs[0], (outs[1] + 1) % P], c["inputs"], sp, c["steps"], c["ext"])
+    bad = list(w)
+    bad[1] = list(bad[1])
+    bad[1][3] = (bad[1][3] + 1) % P
+    with pytest.raises(AssertionError):  # invalid trace: C is not a multiple of Z (stark.py:76)
+        po.mk_stark_proof(bad, c["inputs"], sp, c["steps"], c["ext"])
