@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <map>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -35,6 +36,26 @@ fp h_inv(const fp& a) {  // a^(p-2); modp.py:71-79 uses extended Euclid, the res
     b = fp_sqr(b);
   }
   return r;
+}
+fp h_pow_limbs(const fp& a, const uint32_t e[8]) {
+  fp r = fp_one(), b = a;
+  for (int i = 0; i < 256; ++i) {
+    if ((e[i / 32] >> (i % 32)) & 1) r = fp_mul(r, b);
+    b = fp_sqr(b);
+  }
+  return r;
+}
+// 7^((p - 1) / 2^lg): the reference's choice of generator everywhere (stark.py:205, test_fft.py:120)
+fp h_root_of_order_pow2(int lg) {
+  const uint32_t pm1[8] = {0u, 0xfffffea1u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  uint32_t e[8];
+  for (int i = 0; i < 8; ++i) {
+    const int lo = i + lg / 32, sh = lg % 32;
+    uint64_t v = lo < 8 ? pm1[lo] : 0;
+    if (sh) v = (v >> sh) | ((uint64_t)(lo + 1 < 8 ? pm1[lo + 1] : 0) << (32 - sh));
+    e[i] = (uint32_t)v;
+  }
+  return h_pow_limbs(fp_from_u32(7u), e);
 }
 int ilog2(uint64_t n) {
   int k = 0;
@@ -71,13 +92,23 @@ struct sh_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   std::map<std::string, NttPlan*> plans;
-  enum { WS_WIRE = 0, WS_X, WS_Y, WS_NTT, WS_TREE_A, WS_TREE_B, WS_COL_A, WS_COL_B, WS_MISC, WS_PROOF, WS_COUNT };
+  enum {
+    WS_WIRE = 0, WS_X, WS_Y, WS_NTT, WS_TREE_A, WS_TREE_B, WS_COL_A, WS_COL_B, WS_MISC, WS_PROOF,
+    WS_ST_TRACE, WS_ST_P, WS_ST_D, WS_ST_B, WS_ST_T2, WS_ST_SMALL, WS_ST_MTREE, WS_COUNT
+  };
   void* ws[WS_COUNT] = {};
   size_t ws_cap[WS_COUNT] = {};
   // pinned staging for host <-> device copies of caller (pageable) buffers: two slots, double buffered
   uint8_t* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
+  // STARK prover state: NTT_2s(Z3) per (steps, ext); the step-polynomial terms last uploaded; the constraint flag
+  std::map<std::pair<uint64_t, uint32_t>, void*> z3hat;
+  std::vector<uint8_t> terms_key;
+  void* terms_dev = nullptr;
+  uint32_t terms_begin[SHK_STARK_MAX_WIDTH + 1] = {};
+  uint32_t terms_degree = 0;
+  uint32_t* bad_flag = nullptr;
 };
 
 namespace {
@@ -376,46 +407,55 @@ uint64_t fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
   return total + 32 * n;
 }
 
-// FRI commit on device-resident coefficients; see starkhip.h for the layout.
-int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
-            uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* d_proof) {
-  if (!d_coeffs || !d_proof || batch == 0 || !is_pow2(n)) return SH_ERR_INVALID;
-  NttPlan* pl = nullptr;
-  SH_TRY(plan_for(c, root, n, false, &pl));
-  // validate every round before launching anything
-  {
-    uint64_t nn = n, md = maxdeg_plus_1;
-    bool first = true;
-    while (md > 16) {
-      if (nn < 16) return SH_ERR_INVALID;            // the reference cannot merkelize a column of < 4 values
-      if ((nn >> 2) >= (1ull << 24)) return SH_ERR_UNSUPPORTED;  // assert modulus < 2**24 (utils.py:69)
-      const uint32_t s = first ? samples : 40;
-      if (s == 0) return SH_ERR_INVALID;
-      if (exclude == 1) return SH_ERR_INVALID;       // division by zero in the reference (utils.py:90)
-      if (exclude && ((nn >> 2) * (exclude - 1)) / exclude == 0) return SH_ERR_INVALID;
-      nn >>= 2;
-      md >>= 2;
-      first = false;
-    }
+// every round's parameters are checked before anything is launched
+int fri_validate(uint64_t n, uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t samples) {
+  uint64_t nn = n, md = maxdeg_plus_1;
+  bool first = true;
+  while (md > 16) {
+    if (nn < 16) return SH_ERR_INVALID;            // the reference cannot merkelize a column of < 4 values
+    if ((nn >> 2) >= (1ull << 24)) return SH_ERR_UNSUPPORTED;  // assert modulus < 2**24 (utils.py:69)
+    const uint32_t s = first ? samples : 40;
+    if (s == 0) return SH_ERR_INVALID;
+    if (exclude == 1) return SH_ERR_INVALID;       // division by zero in the reference (utils.py:90)
+    if (exclude && ((nn >> 2) * (exclude - 1)) / exclude == 0) return SH_ERR_INVALID;
+    nn >>= 2;
+    md >>= 2;
+    first = false;
   }
-  const uint64_t stride = fri_proof_len(n, maxdeg_plus_1, samples);
+  return SH_OK;
+}
+
+struct FriBuffers {
+  fp *vals, *next;
+  uint32_t *tree, *tree2, *ys;
+};
+int fri_buffers(sh_ctx* c, uint64_t n, uint32_t batch, uint32_t samples, FriBuffers* b) {
   void *va, *vb, *ta, *tb, *misc;
   SH_TRY(ws_get(c, sh_ctx::WS_COL_A, (size_t)batch * n * sizeof(fp), &va));
   SH_TRY(ws_get(c, sh_ctx::WS_COL_B, (size_t)batch * (n / 4 + 1) * sizeof(fp), &vb));
   SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)batch * 2 * n * 32, &ta));
   SH_TRY(ws_get(c, sh_ctx::WS_TREE_B, (size_t)batch * 2 * (n / 4 + 1) * 32, &tb));
   SH_TRY(ws_get(c, sh_ctx::WS_MISC, (size_t)batch * (samples > 40 ? samples : 40) * 4 + 64, &misc));
-  fp* vals = reinterpret_cast<fp*>(va);
-  fp* next = reinterpret_cast<fp*>(vb);
-  uint32_t* tree = reinterpret_cast<uint32_t*>(ta);
-  uint32_t* tree2 = reinterpret_cast<uint32_t*>(tb);
-  // values = fft(f) over the whole domain (fri.py:207-208)
-  SH_TRY(run_ntt(c, pl, d_coeffs, vals, batch));
+  b->vals = reinterpret_cast<fp*>(va);
+  b->next = reinterpret_cast<fp*>(vb);
+  b->tree = reinterpret_cast<uint32_t*>(ta);
+  b->tree2 = reinterpret_cast<uint32_t*>(tb);
+  b->ys = reinterpret_cast<uint32_t*>(misc);
+  return SH_OK;
+}
+
+// The rounds of the FRI commit (fri.py:212-266) on the evaluations in fb.vals (and, when have_tree, their Merkle
+// tree in fb.tree); proof b is written at d_proof + b * stride.
+int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t samples,
+               uint32_t batch, uint8_t* d_proof, uint64_t stride, bool have_tree) {
+  fp* vals = fb.vals;
+  fp* next = fb.next;
+  uint32_t* tree = fb.tree;
+  uint32_t* tree2 = fb.tree2;
   uint64_t nn = n, md = maxdeg_plus_1, off = 0;
   uint32_t round = 0;
   const fp inv_i = h_pow(pl->root, 3 * (n / 4));  // I^-1 = I^3, I = root^(n/4)
   const fp inv_4 = h_inv(fp_from_u32(4u));
-  bool have_tree = false;
   while (md > 16) {
     const uint32_t s = round == 0 ? samples : 40;
     if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream));  // m = merkelize(values), fri.py:224
@@ -443,7 +483,7 @@ int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], u
     sa.batch = batch;
     sa.samples = s;
     sa.exclude = exclude;
-    sa.ys = reinterpret_cast<uint32_t*>(misc);
+    sa.ys = fb.ys;
     sa.proof = d_proof;
     sa.proof_stride = stride;
     sa.round_off = off;
@@ -463,6 +503,177 @@ int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], u
   return SH_OK;
 }
 
+// FRI commit on device-resident coefficients; see starkhip.h for the layout.
+int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
+            uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* d_proof) {
+  if (!d_coeffs || !d_proof || batch == 0 || !is_pow2(n)) return SH_ERR_INVALID;
+  NttPlan* pl = nullptr;
+  SH_TRY(plan_for(c, root, n, false, &pl));
+  SH_TRY(fri_validate(n, maxdeg_plus_1, exclude, samples));
+  FriBuffers fb;
+  SH_TRY(fri_buffers(c, n, batch, samples, &fb));
+  // values = fft(f) over the whole domain (fri.py:207-208)
+  SH_TRY(run_ntt(c, pl, d_coeffs, fb.vals, batch));
+  return fri_rounds(c, pl, fb, n, maxdeg_plus_1, exclude, samples, batch, d_proof,
+                    fri_proof_len(n, maxdeg_plus_1, samples), false);
+}
+
+// ---- STARK.mk_proof (stark.py:233-279) -----------------------------------------------------------------
+uint64_t stark_header_len(uint64_t n, uint32_t width, uint32_t samples) {
+  const uint64_t lg = (uint64_t)ilog2(n), k = 3ull * width;
+  return 64 + (uint64_t)samples * 32 * (2 * (2 * k + (lg - 1)) + (lg + 1));
+}
+
+int stark_check_shape(uint64_t steps, uint32_t ext, uint32_t width, uint32_t degree, uint32_t samples) {
+  if (!is_pow2(steps) || !is_pow2(ext) || steps < 2 || ext < 2 || width == 0 || samples == 0) return SH_ERR_INVALID;
+  if (width > SHK_STARK_MAX_WIDTH) return SH_ERR_UNSUPPORTED;
+  if (steps > (1ull << 24) || steps * ext >= (1ull << 24)) return SH_ERR_UNSUPPORTED;  // utils.py:69 (spot-check sampling)
+  if ((uint64_t)degree * (steps - 1) + 1 >= steps * ext) return SH_ERR_UNSUPPORTED;   // C (X - x_last) must fit the domain
+  return fri_validate(steps * ext, steps * degree, ext, 40);
+}
+
+// Parse + upload the step polynomials' terms (skipped when they equal the previous call's).
+int stark_terms(sh_ctx* c, uint32_t width, const uint8_t* coefs, const uint8_t* exps, const uint32_t* counts) {
+  if (!coefs || !exps || !counts) return SH_ERR_INVALID;
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < width; ++d) total += counts[d];
+  if (total == 0 || total > 256) return total ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
+  std::vector<uint8_t> key;
+  key.push_back((uint8_t)width);
+  key.insert(key.end(), reinterpret_cast<const uint8_t*>(counts), reinterpret_cast<const uint8_t*>(counts + width));
+  key.insert(key.end(), coefs, coefs + 32 * total);
+  key.insert(key.end(), exps, exps + (size_t)width * total);
+  if (c->terms_dev && key == c->terms_key) return SH_OK;
+  uint32_t degree = 0;
+  for (uint64_t t = 0; t < total; ++t) {
+    uint32_t sum = 0;
+    for (uint32_t v = 0; v < width; ++v) sum += exps[t * width + v];
+    if (sum > degree) degree = sum;  // MultivariatePolynomial.degree (multivariate_polynomial.py:111-117)
+  }
+  std::vector<fp> lim(total);
+  for (uint64_t t = 0; t < total; ++t) lim[t] = h_from_wire(coefs + 32 * t);
+  constexpr size_t CAP = 256 * sizeof(fp) + 256 * SHK_STARK_MAX_WIDTH;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // earlier launches may still read the old terms
+  if (!c->terms_dev) HIP_TRY(c, hipMalloc(&c->terms_dev, CAP));
+  HIP_TRY(c, hipMemcpy(c->terms_dev, lim.data(), total * sizeof(fp), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(reinterpret_cast<uint8_t*>(c->terms_dev) + 256 * sizeof(fp), exps, (size_t)width * total,
+                       hipMemcpyHostToDevice));
+  c->terms_begin[0] = 0;
+  for (uint32_t d = 0; d < width; ++d) c->terms_begin[d + 1] = c->terms_begin[d] + counts[d];
+  c->terms_degree = degree;
+  c->terms_key.swap(key);
+  return SH_OK;
+}
+
+int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t ext, uint32_t width, uint32_t samples,
+              uint32_t batch, uint8_t* d_proof) {
+  const uint32_t degree = c->terms_degree;
+  SH_TRY(stark_check_shape(steps, ext, width, degree, samples));
+  if (!d_wit || !d_inputs || !d_proof || batch == 0) return SH_ERR_INVALID;
+  const uint64_t n = steps * ext, cols = (uint64_t)batch * width;
+  if (cols > 0xffffffffull) return SH_ERR_UNSUPPORTED;
+  const fp g2 = h_root_of_order_pow2(ilog2(n));           // stark.py:205
+  uint8_t g2b[32], g1b[32], hb[32];
+  h_to_wire(g2, g2b);
+  h_to_wire(h_pow(g2, ext), g1b);                          // G1 = G2^ext (stark.py:208)
+  h_to_wire(h_pow(g2, ext / 2), hb);                       // order 2 steps: the domain of the boundary product
+  NttPlan *fwd_n, *inv_n, *inv_s, *fwd_2s, *inv_2s;
+  SH_TRY(plan_for(c, g2b, n, false, &fwd_n));
+  SH_TRY(plan_for(c, g2b, n, true, &inv_n));
+  SH_TRY(plan_for(c, g1b, steps, true, &inv_s));
+  SH_TRY(plan_for(c, hb, 2 * steps, false, &fwd_2s));
+  SH_TRY(plan_for(c, hb, 2 * steps, true, &inv_2s));
+  const fp x_last = h_pow(g2, (steps - 1) * ext);          // stark.py:212
+  const fp inv_last_m1 = h_inv(fp_sub(x_last, fp_one()));
+  const fp cpow = h_pow(h_pow(g2, steps), n - 1);          // `powers[i]` after the loop: (G2^steps)^(precision-1) (stark.py:150-158)
+
+  void *pe, *dw, *bw, *t2, *small, *mt;
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_P, cols * n * sizeof(fp), &pe));
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_D, cols * n * sizeof(fp), &dw));
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_B, cols * n * sizeof(fp), &bw));
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_T2, cols * 2 * steps * sizeof(fp), &t2));
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_MTREE, (size_t)batch * 2 * n * 32, &mt));
+  const size_t iab_bytes = cols * 2 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp);
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_SMALL, iab_bytes + scal_bytes + (size_t)batch * samples * 4, &small));
+  fp* iab = reinterpret_cast<fp*>(small);
+  fp* scal = reinterpret_cast<fp*>(reinterpret_cast<uint8_t*>(small) + iab_bytes);
+  uint32_t* ys = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(small) + iab_bytes + scal_bytes);
+  if (!c->bad_flag) {
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bad_flag), 64));
+    HIP_TRY(c, hipMemsetAsync(c->bad_flag, 0, 64, c->stream));
+  }
+  // Z3's transform over the 2 steps domain, once per (steps, ext)
+  fp* z3 = nullptr;
+  {
+    const auto key = std::make_pair(steps, ext);
+    auto it = c->z3hat.find(key);
+    if (it == c->z3hat.end()) {
+      void* z = nullptr;
+      HIP_TRY(c, hipMalloc(&z, 2 * steps * sizeof(fp)));
+      c->z3hat[key] = z;
+      z3 = reinterpret_cast<fp*>(z);
+      HIP_TRY(c, shk_stark_z3(z3, steps, ext, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, fp_neg(inv_last_m1), c->stream));
+      SH_TRY(run_ntt(c, fwd_2s, z3, z3, 1));
+    } else {
+      z3 = reinterpret_cast<fp*>(it->second);
+    }
+  }
+  StarkArgs a;
+  memset(&a, 0, sizeof a);
+  a.p_evals = reinterpret_cast<fp*>(pe);
+  a.d_work = reinterpret_cast<fp*>(dw);
+  a.b_work = reinterpret_cast<fp*>(bw);
+  a.n = n;
+  a.ext = ext;
+  a.width = width;
+  a.batch = batch;
+  a.tw_lo = fwd_n->base.lo;
+  a.tw_hi = fwd_n->base.hi;
+  a.tw_lb = fwd_n->base.lb;
+  a.x_last = x_last;
+  a.term_coef = reinterpret_cast<const fp*>(c->terms_dev);
+  a.term_exps = reinterpret_cast<const uint8_t*>(c->terms_dev) + 256 * sizeof(fp);
+  memcpy(a.term_begin, c->terms_begin, sizeof a.term_begin);
+  fp* P = reinterpret_cast<fp*>(pe);
+
+  // boundary interpolants need witness[dim][-1] before the trace becomes coefficients (stark.py:91-96)
+  HIP_TRY(c, shk_stark_interp(d_wit, d_inputs, steps, (uint32_t)cols, inv_last_m1, iab, c->stream));
+  // trace polynomials and their evaluations: the low-degree extension (stark.py:27-36, 253-256)
+  SH_TRY(run_ntt(c, inv_s, d_wit, d_wit, (uint32_t)cols));
+  HIP_TRY(c, shk_pad_copy(d_wit, P, steps, n, (uint32_t)cols, c->stream));
+  SH_TRY(run_ntt(c, fwd_n, P, P, (uint32_t)cols));
+  // D = C / Z (stark.py:38-79): C (X - x_last) pointwise, coefficients, divide by X^steps - 1, evaluate
+  HIP_TRY(c, shk_stark_constraints(a, c->stream));
+  SH_TRY(run_ntt(c, inv_n, a.d_work, a.d_work, (uint32_t)cols));
+  HIP_TRY(c, shk_stark_divide(a.d_work, steps, ext, cols, c->bad_flag, c->stream));
+  SH_TRY(run_ntt(c, fwd_n, a.d_work, a.d_work, (uint32_t)cols));
+  // B = (P - I) / Z2 (stark.py:81-104): (P - I) Z3 over the 2 steps domain, upper half, evaluate
+  fp* T2 = reinterpret_cast<fp*>(t2);
+  HIP_TRY(c, shk_stark_bprep(d_wit, iab, T2, steps, cols, c->stream));
+  SH_TRY(run_ntt(c, fwd_2s, T2, T2, (uint32_t)cols));
+  HIP_TRY(c, shk_mul_bcast(T2, z3, 2 * steps, cols, c->stream));
+  SH_TRY(run_ntt(c, inv_2s, T2, T2, (uint32_t)cols));
+  HIP_TRY(c, shk_stark_bextract(T2, a.b_work, steps, n, cols, c->stream));
+  SH_TRY(run_ntt(c, fwd_n, a.b_work, a.b_work, (uint32_t)cols));
+  // mtree = merkelize_polynomial_evaluations(width, P + D + B evaluations) (stark.py:257)
+  uint32_t* mtree = reinterpret_cast<uint32_t*>(mt);
+  HIP_TRY(c, shk_stark_merkelize(a, mtree, c->stream));
+  // l = pseudorandom linear combination keyed by mtree's root (stark.py:128-177, 259-263), on evaluations
+  FriBuffers fb;
+  SH_TRY(fri_buffers(c, n, batch, samples, &fb));
+  HIP_TRY(c, shk_stark_scalars(mtree, 2 * n * 8, width, batch, cpow, scal, c->stream));
+  HIP_TRY(c, shk_stark_lincomb(a, scal, fb.vals, c->stream));
+  HIP_TRY(c, shk_merkelize(fb.vals, false, n, batch, fb.tree, c->stream));   // l_mtree
+  // spot checks (stark.py:390-402)
+  const uint64_t stride = stark_header_len(n, width, samples) + fri_proof_len(n, steps * (uint64_t)degree, 40);
+  HIP_TRY(c, shk_sample_indices(fb.tree, 2 * n * 8, (uint32_t)n, batch, samples, ext, ys, c->stream));
+  HIP_TRY(c, shk_stark_gather(a, mtree, fb.tree, ys, samples, d_proof, stride, c->stream));
+  // fri.generate_proximity_proof(l_poly, G2, steps * degree, exclude_multiples_of=ext) (stark.py:271-276); its first
+  // tree is l_mtree
+  return fri_rounds(c, fwd_n, fb, n, steps * (uint64_t)degree, ext, 40, batch, d_proof + stark_header_len(n, width, samples),
+                    stride, true);
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -477,6 +688,7 @@ const char* sh_strerror(int status) {
     case SH_ERR_NOMEM: return "out of memory";
     case SH_ERR_TOO_SMALL: return "output buffer too small";
     case SH_ERR_UNSUPPORTED: return "unsupported size";
+    case SH_ERR_CONSTRAINT: return "the witness violates a transition constraint";
     case SH_ERR_NO_DEVICE: return "no usable gfx950 device";
     default: return "unknown status";
   }
@@ -514,6 +726,9 @@ void sh_ctx_destroy(sh_ctx* c) {
   }
   for (int i = 0; i < sh_ctx::WS_COUNT; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
+  for (auto& kv : c->z3hat) (void)hipFree(kv.second);
+  if (c->terms_dev) (void)hipFree(c->terms_dev);
+  if (c->bad_flag) (void)hipFree(c->bad_flag);
   for (int i = 0; i < 2; ++i) {
     if (c->pin[i]) (void)hipHostFree(c->pin[i]);
     if (c->pin_ev[i]) (void)hipEventDestroy(c->pin_ev[i]);
@@ -806,6 +1021,56 @@ int sh_fri_prove(sh_ctx* c, const uint8_t* coeffs, uint64_t n_coeffs, uint64_t n
   SH_TRY(ws_get(c, sh_ctx::WS_PROOF, (size_t)stride * batch, &dp));
   SH_TRY(run_fri(c, x, n, root, maxdeg_plus_1, exclude, samples, batch, reinterpret_cast<uint8_t*>(dp)));
   return d2h(c, proof, dp, (size_t)stride * batch);
+}
+
+uint64_t sh_stark_proof_len(uint64_t steps, uint32_t ext, uint32_t width, uint32_t degree, uint32_t samples) {
+  if (stark_check_shape(steps, ext, width, degree, samples) != SH_OK) return 0;
+  const uint64_t n = steps * ext;
+  return stark_header_len(n, width, samples) + fri_proof_len(n, steps * (uint64_t)degree, 40);
+}
+
+int sh_stark_status(sh_ctx* c) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (!c->bad_flag) return SH_OK;
+  uint32_t flag = 0;
+  HIP_TRY(c, hipMemcpy(&flag, c->bad_flag, 4, hipMemcpyDeviceToHost));
+  if (!flag) return SH_OK;
+  HIP_TRY(c, hipMemset(c->bad_flag, 0, 4));
+  return SH_ERR_CONSTRAINT;
+}
+
+int sh_dev_stark_prove(sh_ctx* c, void* d_witness, const void* d_inputs, uint64_t steps, uint32_t ext, uint32_t width,
+                       const uint8_t* term_coefs, const uint8_t* term_exps, const uint32_t* term_counts, uint32_t samples,
+                       uint32_t batch, void* d_proof) {
+  if (!c || width == 0 || width > SHK_STARK_MAX_WIDTH) return c && width > SHK_STARK_MAX_WIDTH ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(stark_terms(c, width, term_coefs, term_exps, term_counts));
+  return run_stark(c, reinterpret_cast<fp*>(d_witness), reinterpret_cast<const fp*>(d_inputs), steps, ext, width, samples,
+                   batch, reinterpret_cast<uint8_t*>(d_proof));
+}
+
+int sh_stark_prove(sh_ctx* c, const uint8_t* witness, const uint8_t* inputs, uint64_t steps, uint32_t ext, uint32_t width,
+                   const uint8_t* term_coefs, const uint8_t* term_exps, const uint32_t* term_counts, uint32_t samples,
+                   uint32_t batch, uint8_t* proof, uint64_t proof_cap) {
+  if (!c || !witness || !inputs || !proof || batch == 0 || width == 0) return SH_ERR_INVALID;
+  if (width > SHK_STARK_MAX_WIDTH) return SH_ERR_UNSUPPORTED;
+  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(stark_terms(c, width, term_coefs, term_exps, term_counts));
+  SH_TRY(stark_check_shape(steps, ext, width, c->terms_degree, samples));
+  const uint64_t n = steps * ext;
+  const uint64_t stride = stark_header_len(n, width, samples) + fri_proof_len(n, steps * (uint64_t)c->terms_degree, 40);
+  if (proof_cap < stride * batch) return SH_ERR_TOO_SMALL;
+  const uint64_t cols = (uint64_t)batch * width;
+  fp *w = nullptr, *in = nullptr;
+  SH_TRY(upload_padded(c, witness, steps, steps, (uint32_t)cols, sh_ctx::WS_ST_TRACE, &w));
+  SH_TRY(upload_padded(c, inputs, 1, 1, (uint32_t)cols, sh_ctx::WS_Y, &in));
+  void* dp = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_PROOF, (size_t)stride * batch, &dp));
+  SH_TRY(run_stark(c, w, in, steps, ext, width, samples, batch, reinterpret_cast<uint8_t*>(dp)));
+  SH_TRY(d2h(c, proof, dp, (size_t)stride * batch));
+  return sh_stark_status(c);
 }
 
 }  // extern "C"

@@ -78,6 +78,44 @@ struct SampleArgs {
   uint64_t round_off;        // byte offset of this round inside a proof
 };
 hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st);
+// ys[b][0..samples) = get_pseudorandom_indices(node 1 of tree b, modulus, samples, exclude) (utils.py:60-90);
+// trees are tree_words u32 apart
+hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint32_t modulus, uint32_t batch,
+                              uint32_t samples, uint32_t exclude, uint32_t* d_ys, hipStream_t st);
 // final layer: canonical wire form of values[b][0..n) into proof[b] + off
 hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,
                          uint64_t off, hipStream_t st);
+
+// ---- stark.hip: constraint / boundary quotients, packed tree, linear combination, spot checks (stark.py:233-279) ----
+constexpr uint32_t SHK_STARK_MAX_WIDTH = 9;  // get_pseudorandom_ks returns None from 10 on (stark.py:106-126)
+struct StarkArgs {
+  const fp* p_evals;  // [batch * width][n]  trace polynomials on the G2 domain
+  fp* d_work;         // [batch * width][n]  C (X - x_last) evaluations -> coefficients -> D coefficients -> D evaluations
+  fp* b_work;         // [batch * width][n]  B coefficients -> B evaluations
+  uint64_t n;         // precision = steps * ext
+  uint32_t ext;
+  uint32_t width;
+  uint32_t batch;
+  const fp* tw_lo;    // powers of G2: G2^e = lo[e & mask] (* hi[e >> lb] when hi)
+  const fp* tw_hi;
+  uint32_t tw_lb;
+  fp x_last;          // G2^((steps - 1) ext)  (stark.py:212)
+  const fp* term_coef;     // step polynomials: term t = coef[t] * prod_v X_v^exps[t][v]
+  const uint8_t* term_exps;
+  uint32_t term_begin[SHK_STARK_MAX_WIDTH + 1];  // terms of dimension c: [term_begin[c], term_begin[c+1])
+};
+hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, uint32_t cols, const fp& inv_last_m1, fp* iab,
+                            hipStream_t st);
+hipError_t shk_stark_constraints(const StarkArgs& a, hipStream_t st);
+hipError_t shk_stark_divide(fp* e, uint64_t steps, uint32_t ext, uint64_t cols, uint32_t* bad, hipStream_t st);
+hipError_t shk_stark_z3(fp* out, uint64_t steps, uint32_t ext, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb,
+                        const fp& inv_1_m_last, hipStream_t st);
+hipError_t shk_stark_bprep(const fp* pcoef, const fp* iab, fp* t2, uint64_t steps, uint64_t cols, hipStream_t st);
+hipError_t shk_mul_bcast(fp* a, const fp* b, uint64_t len, uint64_t cols, hipStream_t st);
+hipError_t shk_stark_bextract(const fp* t2, fp* dst, uint64_t steps, uint64_t n, uint64_t cols, hipStream_t st);
+hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st);
+hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
+                             fp* d_scal, hipStream_t st);
+hipError_t shk_stark_lincomb(const StarkArgs& a, const fp* d_scal, fp* d_l, hipStream_t st);
+hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const uint32_t* d_ys,
+                            uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st);

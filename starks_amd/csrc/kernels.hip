@@ -294,38 +294,38 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
 }
 
 // ---- query sampling + branch gather --------------------------------------------------------------------
-// get_pseudorandom_indices(m2[1], q, samples, exclude_multiples_of) (utils.py:60-90): one QUAD of lanes per proof.
+// get_pseudorandom_indices(root, modulus, samples, exclude_multiples_of) (utils.py:60-90): one QUAD of lanes per proof.
 // data = root, then data += blake(data[-32:]) (utils.py:74-75): a serial chain, so each 32-byte block is hashed
 // with the low-latency quad-lane BLAKE2s; after block k lane q holds words q and 4+q = samples 8k+q and 8k+4+q.
-__global__ void __launch_bounds__(64) fri_sample_kernel(SampleArgs a) {
+__global__ void __launch_bounds__(64) sample_indices_kernel(const uint32_t* nodes, uint64_t tree_words, uint32_t modulus,
+                                                            uint32_t batch, uint32_t samples, uint32_t exclude,
+                                                            uint32_t* ys_out) {
   __shared__ __attribute__((aligned(16))) uint32_t slots[16 * 16];
   const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
   const uint32_t b = blockIdx.x * 16 + quad;
-  const bool live = b < a.batch;
-  const uint64_t qn = a.n >> 2;
+  const bool live = b < batch;
   b2q_addr ad;
   b2q_addr_init(ad, quad * 64, q);
   uint32_t w_lo = 0, w_hi = 0;
   if (live) {
-    const uint32_t* root = a.nodes_m2 + ((uint64_t)b * 2 * qn + 1) * 8;  // entropy = root of the column tree
+    const uint32_t* root = nodes + (uint64_t)b * tree_words + 8;  // entropy = node 1 of proof b's tree
     w_lo = root[q];
     w_hi = root[4 + q];
   }
   uint32_t* slot = slots + quad * 16;
   slot[8 + q] = 0;   // a 32-byte message: words 8..15 are zero padding
   slot[12 + q] = 0;
-  const uint32_t modulus = (uint32_t)qn;
-  const uint32_t real = a.exclude ? (uint32_t)(((uint64_t)modulus * (a.exclude - 1)) / a.exclude) : modulus;
-  uint32_t* ys = a.ys + (uint64_t)b * a.samples;
-  const uint32_t blocks = (a.samples + 7) / 8;
+  const uint32_t real = exclude ? (uint32_t)(((uint64_t)modulus * (exclude - 1)) / exclude) : modulus;
+  uint32_t* ys = ys_out + (uint64_t)b * samples;
+  const uint32_t blocks = (samples + 7) / 8;
   for (uint32_t k = 0; k < blocks; ++k) {
     if (live) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const uint32_t j = 8 * k + 4 * half + q;
-        if (j < a.samples) {
+        if (j < samples) {
           const uint32_t x = __builtin_bswap32(half ? w_hi : w_lo) % real;  // int.from_bytes(data[4j:4j+4], 'big') % modulus
-          ys[j] = a.exclude ? x + 1 + x / (a.exclude - 1) : x;
+          ys[j] = exclude ? x + 1 + x / (exclude - 1) : x;
         }
       }
     }
@@ -458,9 +458,15 @@ hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(fri_fold_kernel, dim3(grid_for(work)), dim3(TPB), 0, st, a);
   return hipGetLastError();
 }
+hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint32_t modulus, uint32_t batch,
+                              uint32_t samples, uint32_t exclude, uint32_t* d_ys, hipStream_t st) {
+  hipLaunchKernelGGL(sample_indices_kernel, dim3((batch + 15) / 16), dim3(64), 0, st, d_nodes, tree_words, modulus, batch,
+                     samples, exclude, d_ys);
+  return hipGetLastError();
+}
 hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(fri_sample_kernel, dim3((a.batch + 15) / 16), dim3(64), 0, st, a);
-  hipError_t e = hipGetLastError();
+  hipError_t e = shk_sample_indices(a.nodes_m2, 2 * (a.n >> 2) * 8, (uint32_t)(a.n >> 2), a.batch, a.samples, a.exclude,
+                                    a.ys, st);  // entropy = root of the column tree
   if (e != hipSuccess) return e;
   uint32_t l1 = 1, l2;
   while ((1ull << (l1 - 1)) < a.n) ++l1;  // log2(n) + 1

@@ -1,0 +1,372 @@
+// stark.hip -- the kernels between the low-degree extension and the FRI commit in STARK.mk_proof
+// (starks/stark.py:233-279): transition-constraint quotient D, boundary quotient B, the packed Merkle tree over
+// (P, D, B), the pseudorandom linear combination and the Merkle spot checks.
+//
+// The reference builds C = P(g1 X) - step(P), D = C / Z and B = (P - I) / Z2 in COEFFICIENT form with schoolbook
+// polynomial arithmetic (O(n^2), stark.py:38-104) and then evaluates them.  Here every product is pointwise on the
+// evaluation domain G2 (N = steps * ext points) and every division is by X^steps - 1, which is a stride-`steps`
+// recurrence on coefficients:
+//   D = C (X - x_last) / (X^steps - 1)             [Z  = (X^steps - 1) / (X - x_last),            stark.py:69-72]
+//   B = (P - I) Z3 / (X^steps - 1)                 [Z2 = (X - 1)(X - x_last), Z3 = (X^steps - 1) / Z2, stark.py:89]
+// with the exact polynomial quotients (not pointwise 0/0 at the trace points), so the committed evaluations and
+// therefore every Merkle root and proof byte equal the reference's.
+#include <stdlib.h>
+
+#include "blake2s.cuh"
+#include "internal.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+
+inline unsigned grid_for(uint64_t work, int tpb = TPB) { return (unsigned)((work + tpb - 1) / tpb); }
+
+__device__ __forceinline__ void load8(const uint32_t* p, uint32_t w[8]) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint32_t* p, const uint32_t w[8]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+// g^e from a two-level power table
+__device__ __forceinline__ fp pow_lookup(const fp* lo, const fp* hi, uint32_t lb, uint64_t e) {
+  fp v = fp_load(lo + (e & ((1ull << lb) - 1)));
+  if (hi) v = fp_mul(v, fp_load(hi + (e >> lb)));
+  return v;
+}
+
+// ---- boundary interpolant (stark.py:81-96, poly_utils.py:397-410) -----------------------------------------
+// I_c(X) = a + b X through (1, input_c) and (x_last, output_c), output_c = witness[c][steps - 1]:
+// b = (output - input) / (x_last - 1), a = input - b.  One thread per column; run BEFORE the trace is transformed.
+__global__ void __launch_bounds__(TPB) stark_interp_kernel(const fp* trace, const fp* inputs, uint64_t steps, uint32_t cols,
+                                                           fp inv_last_m1, fp* iab) {
+  const uint32_t c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= cols) return;
+  const fp in = fp_load(inputs + c);
+  const fp out = fp_load(trace + (uint64_t)c * steps + (steps - 1));
+  const fp b = fp_mul(fp_sub(out, in), inv_last_m1);
+  fp_store(iab + 2 * c, fp_sub(in, b));
+  fp_store(iab + 2 * c + 1, b);
+}
+
+// ---- transition constraints on the evaluation domain (stark.py:38-57) --------------------------------------
+// cz[c][i] = (P_c(g1 x_i) - step_c(P_1(x_i) .. P_W(x_i))) * (x_i - x_last),  x_i = G2^i,  P_c(g1 x_i) = P_c[x_(i+ext)].
+// step_c = sum over its terms of coef * prod_v X_v^exps[v] (multivariate_polynomial.py:329-338).
+template <int W>
+__global__ void __launch_bounds__(TPB) stark_constraint_kernel(StarkArgs a) {
+  const uint64_t N = a.n;
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= N * a.batch) return;
+  const uint64_t b = g / N, i = g - b * N;
+  const fp* pe = a.p_evals + b * W * N;
+  fp P[W];
+#pragma unroll
+  for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + i);
+  const fp xm = fp_sub(pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i), a.x_last);
+  const uint64_t inext = (i + a.ext) & (N - 1);
+#pragma unroll 1
+  for (int c = 0; c < W; ++c) {
+    fp acc = fp_zero();
+    for (uint32_t t = a.term_begin[c]; t < a.term_begin[c + 1]; ++t) {
+      fp prod = fp_load(a.term_coef + t);
+      const uint8_t* ex = a.term_exps + (uint64_t)t * W;
+#pragma unroll
+      for (int v = 0; v < W; ++v) {
+        const uint32_t e = ex[v];
+        for (uint32_t k = 0; k < e; ++k) prod = fp_mul(prod, P[v]);
+      }
+      acc = fp_add(acc, prod);
+    }
+    const fp nxt = fp_load(pe + (uint64_t)c * N + inext);
+    fp_store(a.d_work + (b * W + c) * N + i, fp_mul(fp_sub(nxt, acc), xm));
+  }
+}
+
+// ---- exact division by X^steps - 1 on coefficients ---------------------------------------------------------
+// e = coefficients of E = Q (X^s - 1), N of them: q_k = e_(k+s) + q_(k+s), q_k = 0 for k >= N - s.  One thread per
+// (column, residue k mod s) walks its chain from the top; the remainder e_r + q_r must vanish, otherwise the
+// witness violates a transition constraint (the reference asserts `cp % z == 0`, stark.py:76) -> *bad = 1.
+__global__ void __launch_bounds__(TPB) stark_divide_kernel(fp* e, uint64_t steps, uint32_t ext, uint64_t cols, uint32_t* bad) {
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= cols * steps) return;
+  const uint64_t c = g / steps, r = g - c * steps;
+  fp* col = e + c * steps * ext;
+  fp qn = fp_zero();
+  fp en = fp_load(col + r + (uint64_t)(ext - 1) * steps);
+  fp_store(col + r + (uint64_t)(ext - 1) * steps, qn);
+  for (uint32_t m = ext - 1; m-- > 0;) {
+    const uint64_t k = r + (uint64_t)m * steps;
+    const fp ek = fp_load(col + k);
+    const fp qk = fp_add(en, qn);
+    fp_store(col + k, qk);
+    en = ek;
+    qn = qk;
+  }
+  const fp rem = fp_canon(fp_add(en, qn));
+  uint32_t nz = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) nz |= rem.v[j];
+  if (nz) atomicOr(bad, 1u);
+}
+
+// ---- boundary quotient --------------------------------------------------------------------------------------
+// Z3 = (X^s - 1) / ((X - 1)(X - r)), r = x_last = g1^-1, has the closed form  z3_k = (1 - g1^(k+1)) / (1 - r), k < s
+// (partial fractions of 1/((X-1)(X-r)) times the two geometric sums).  out: 2s coefficients, upper half zero.
+__global__ void __launch_bounds__(TPB) stark_z3_kernel(fp* out, uint64_t steps, uint32_t ext, const fp* tw_lo, const fp* tw_hi,
+                                                       uint32_t tw_lb, fp inv_1_m_last) {
+  const uint64_t k = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (k >= 2 * steps) return;
+  fp v = fp_zero();
+  if (k < steps) {
+    const uint64_t e = ((k + 1) & (steps - 1)) * ext;  // g1^(k+1) = G2^(ext (k+1 mod s))
+    v = fp_mul(fp_sub(fp_one(), pow_lookup(tw_lo, tw_hi, tw_lb, e)), inv_1_m_last);
+  }
+  fp_store(out + k, v);
+}
+// t2[c][k] = coefficient k of P_c - I_c for k < s, zero for s <= k < 2s
+__global__ void __launch_bounds__(TPB) stark_bprep_kernel(const fp* pcoef, const fp* iab, fp* t2, uint64_t steps, uint64_t cols) {
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= cols * 2 * steps) return;
+  const uint64_t c = g / (2 * steps), k = g - c * 2 * steps;
+  fp v = fp_zero();
+  if (k < steps) {
+    v = fp_load(pcoef + c * steps + k);
+    if (k < 2) v = fp_sub(v, fp_load(iab + 2 * c + k));
+  }
+  fp_store(t2 + g, v);
+}
+// a[c][k] *= b[k]
+__global__ void __launch_bounds__(TPB) mul_bcast_kernel(fp* a, const fp* b, uint64_t len, uint64_t total) {
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= total) return;
+  fp_store(a + g, fp_mul(fp_load(a + g), fp_load(b + (g % len))));
+}
+// (P - I) Z3 = Q (X^s - 1) with deg Q < s, so Q's coefficients are the product's upper half; dst = Q zero-padded to n
+__global__ void __launch_bounds__(TPB) stark_bextract_kernel(const fp* t2, fp* dst, uint64_t steps, uint64_t n, uint64_t cols) {
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= cols * n) return;
+  const uint64_t c = g / n, k = g - c * n;
+  fp_store(dst + g, k < steps ? fp_load(t2 + c * 2 * steps + steps + k) : fp_zero());
+}
+
+// ---- packed Merkle leaves (merkle_tree.py:94-119) over limb-form evaluations ---------------------------------
+// Leaf x of proof b = P_1(x) .. P_W(x) || D_1(x) .. D_W(x) || B_1(x) .. B_W(x), each 32 bytes big-endian
+// (stark.py:251-257).  Element e of the leaf:
+__device__ __forceinline__ void leaf_elem(const StarkArgs& a, uint64_t b, uint32_t e, uint64_t x, uint32_t w[8]) {
+  const uint32_t W = a.width;
+  const fp* base = e < W ? a.p_evals : e < 2 * W ? a.d_work : a.b_work;
+  const uint32_t c = e < W ? e : e < 2 * W ? e - W : e - 2 * W;
+  fp_to_wire_words(fp_canon(fp_load(base + (b * W + c) * a.n + x)), w);
+}
+// One thread per permute4 row: hashes the two leaf pairs (k = 3W BLAKE2s blocks each) and their parent.
+// nodes: [batch][2n] x 32 B (only [0, n) is written: the leaves stay in the evaluation arrays).
+__global__ void __launch_bounds__(TPB) stark_leaves_kernel(StarkArgs a, uint32_t* nodes) {
+  const uint64_t n = a.n, q = n >> 2;
+  const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  const uint64_t b = blockIdx.y;
+  if (i >= q) return;
+  const uint32_t k = 3 * a.width;
+  uint32_t* tree = nodes + b * 2 * n * 8;
+  b2digest d[2];
+#pragma unroll 1
+  for (int s = 0; s < 2; ++s) {
+    b2_init(d[s].h);
+    const uint64_t la = i + (uint64_t)(2 * s) * q, lb = i + (uint64_t)(2 * s + 1) * q;
+    for (uint32_t blk = 0; blk < k; ++blk) {
+      uint32_t m[16];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const uint32_t e = 2 * blk + half;  // element index inside leafA || leafB
+        leaf_elem(a, b, e < k ? e : e - k, e < k ? la : lb, m + 8 * half);
+      }
+      b2_compress(d[s].h, m, 64 * (blk + 1), blk + 1 == k);
+    }
+    store8(tree + (n / 2 + 2 * i + s) * 8, d[s].h);
+  }
+  b2digest top = b2_hash_pair(d[0].h, d[1].h);
+  store8(tree + (n / 4 + i) * 8, top.h);
+  if (i == 0) {
+    uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    store8(tree, z);
+  }
+}
+
+// ---- Fiat-Shamir scalars of the linear combination (stark.py:106-177) ---------------------------------------
+// k_t = int(blake(m_root + b"0x0<t+1>")) (4-byte ASCII suffix); with c = (G2^steps)^(precision-1) -- `powers[i]` in the
+// reference reads the loop variable left over from building the list, i.e. the last power --
+//   l = sum_j (1 + lk_j c) (D_j + (k1 + k2 c) P_j + (k3 + k4 c) B_j),   lk = get_pseudorandom_ks(m_root, width).
+// One 64-thread block per proof: thread t hashes suffix t, threads j < W then write alpha_j, alpha_j beta, alpha_j gamma.
+__global__ void __launch_bounds__(64) stark_scalars_kernel(const uint32_t* mnodes, uint64_t tree_words, uint32_t width, fp cpow,
+                                                           fp* scal) {
+  __shared__ fp ks[16];
+  const uint32_t t = threadIdx.x, b = blockIdx.x;
+  const uint32_t nk = 4 + (width > 4 ? width : 0);  // k1..k4, then (width > 4 only) the "0x00".. series of l_ks
+  if (t < nk) {
+    uint32_t m[16];
+    load8(mnodes + (uint64_t)b * tree_words + 8, m);
+#pragma unroll
+    for (int j = 9; j < 16; ++j) m[j] = 0;
+    const uint32_t digit = t < 4 ? t + 1 : t - 4;  // stark.py:118-125
+    m[8] = 0x30u | (0x78u << 8) | (0x30u << 16) | ((0x30u + digit) << 24);  // "0x0<digit>"
+    b2digest d = b2_hash_short(m, 36);
+    ks[t] = fp_from_wire_words(d.h);
+  }
+  __syncthreads();
+  if (t < width) {
+    const fp lk = width > 4 ? ks[4 + t] : ks[t];
+    const fp beta = fp_add(ks[0], fp_mul(ks[1], cpow));
+    const fp gamma = fp_add(ks[2], fp_mul(ks[3], cpow));
+    const fp alpha = fp_add(fp_one(), fp_mul(lk, cpow));
+    fp* o = scal + ((uint64_t)b * width + t) * 3;
+    fp_store(o, alpha);
+    fp_store(o + 1, fp_mul(alpha, beta));
+    fp_store(o + 2, fp_mul(alpha, gamma));
+  }
+}
+// l[b][i] = sum_j alpha_j D_j[i] + (alpha_j beta) P_j[i] + (alpha_j gamma) B_j[i]
+__global__ void __launch_bounds__(TPB) stark_lincomb_kernel(StarkArgs a, const fp* scal, fp* l_evals) {
+  const uint64_t N = a.n;
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= N * a.batch) return;
+  const uint64_t b = g / N, i = g - b * N;
+  fp acc = fp_zero();
+  for (uint32_t j = 0; j < a.width; ++j) {
+    const uint64_t col = (b * a.width + j) * N + i;
+    const fp* s = scal + (b * a.width + j) * 3;
+    acc = fp_add(acc, fp_mul(fp_load(s), fp_load(a.d_work + col)));
+    acc = fp_add(acc, fp_mul(fp_load(s + 1), fp_load(a.p_evals + col)));
+    acc = fp_add(acc, fp_mul(fp_load(s + 2), fp_load(a.b_work + col)));
+  }
+  fp_store(l_evals + g, acc);
+}
+
+// ---- spot checks (stark.py:390-402) -------------------------------------------------------------------------
+// proof[b] = m_root | l_root | for each sampled pos: mk_branch(mtree, pos) | mk_branch(mtree, pos + ext) | mk_branch(ltree, pos).
+// A packed branch = leaf (k values) | sibling leaf (k values) | log2(n) - 1 nodes; an l branch = log2(n) + 1 nodes.
+// One thread per 32-byte slot.
+__global__ void __launch_bounds__(TPB) stark_gather_kernel(StarkArgs a, const uint32_t* mnodes, const uint32_t* lnodes,
+                                                           const uint32_t* ys, uint32_t samples, uint32_t lg, uint8_t* proof,
+                                                           uint64_t stride) {
+  const uint32_t k = 3 * a.width;
+  const uint32_t pb = 2 * k + (lg - 1), lb = lg + 1, per_sample = 2 * pb + lb;
+  const uint64_t per_proof = 2 + (uint64_t)samples * per_sample;
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= per_proof * a.batch) return;
+  const uint64_t b = g / per_proof;
+  uint64_t r = g - b * per_proof;
+  uint32_t* out = reinterpret_cast<uint32_t*>(proof + b * stride) + 8 * r;
+  const uint64_t n = a.n, q = n >> 2;
+  const uint32_t* mt = mnodes + b * 2 * n * 8;
+  const uint32_t* lt = lnodes + b * 2 * n * 8;
+  uint32_t w[8];
+  if (r < 2) {
+    load8((r == 0 ? mt : lt) + 8, w);
+    store8(out, w);
+    return;
+  }
+  r -= 2;
+  const uint32_t s = (uint32_t)(r / per_sample);
+  uint32_t slot = (uint32_t)(r - (uint64_t)s * per_sample);
+  const uint64_t pos = ys[b * samples + s];
+  if (slot < 2 * pb) {
+    const uint32_t which = slot / pb;
+    slot -= which * pb;
+    const uint64_t x = which ? ((pos + a.ext) & (n - 1)) : pos;
+    const uint64_t idx = x / q + 4 * (x % q);  // get_index_in_permuted (merkle_tree.py:26-33)
+    if (slot < 2 * k) {
+      const uint64_t pi = slot < k ? idx : (idx ^ 1);      // the leaf, then its sibling leaf
+      const uint64_t leaf = (pi & 3) * q + (pi >> 2);      // back to the natural position
+      leaf_elem(a, b, slot < k ? slot : slot - k, leaf, w);
+    } else {
+      const uint32_t lev = slot - 2 * k + 1;               // branch entry lev + 1: tree[((n + idx) >> lev) ^ 1]
+      load8(mt + (((n + idx) >> lev) ^ 1) * 8, w);
+    }
+  } else {
+    slot -= 2 * pb;
+    const uint64_t idx = n + pos / q + 4 * (pos % q);
+    const uint64_t node = slot == 0 ? idx : ((idx >> (slot - 1)) ^ 1);
+    load8(lt + node * 8, w);
+  }
+  store8(out, w);
+}
+
+}  // namespace
+
+hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, uint32_t cols, const fp& inv_last_m1, fp* iab,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(stark_interp_kernel, dim3(grid_for(cols)), dim3(TPB), 0, st, trace, inputs, steps, cols, inv_last_m1, iab);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_constraints(const StarkArgs& a, hipStream_t st) {
+  const dim3 grid(grid_for(a.n * a.batch)), block(TPB);
+  switch (a.width) {
+#define SHK_CASE(W) \
+  case W: hipLaunchKernelGGL(stark_constraint_kernel<W>, grid, block, 0, st, a); break;
+    SHK_CASE(1) SHK_CASE(2) SHK_CASE(3) SHK_CASE(4) SHK_CASE(5) SHK_CASE(6) SHK_CASE(7) SHK_CASE(8) SHK_CASE(9)
+#undef SHK_CASE
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_divide(fp* e, uint64_t steps, uint32_t ext, uint64_t cols, uint32_t* bad, hipStream_t st) {
+  hipLaunchKernelGGL(stark_divide_kernel, dim3(grid_for(cols * steps)), dim3(TPB), 0, st, e, steps, ext, cols, bad);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_z3(fp* out, uint64_t steps, uint32_t ext, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb,
+                        const fp& inv_1_m_last, hipStream_t st) {
+  hipLaunchKernelGGL(stark_z3_kernel, dim3(grid_for(2 * steps)), dim3(TPB), 0, st, out, steps, ext, tw_lo, tw_hi, tw_lb,
+                     inv_1_m_last);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_bprep(const fp* pcoef, const fp* iab, fp* t2, uint64_t steps, uint64_t cols, hipStream_t st) {
+  hipLaunchKernelGGL(stark_bprep_kernel, dim3(grid_for(cols * 2 * steps)), dim3(TPB), 0, st, pcoef, iab, t2, steps, cols);
+  return hipGetLastError();
+}
+
+hipError_t shk_mul_bcast(fp* a, const fp* b, uint64_t len, uint64_t cols, hipStream_t st) {
+  hipLaunchKernelGGL(mul_bcast_kernel, dim3(grid_for(len * cols)), dim3(TPB), 0, st, a, b, len, len * cols);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_bextract(const fp* t2, fp* dst, uint64_t steps, uint64_t n, uint64_t cols, hipStream_t st) {
+  hipLaunchKernelGGL(stark_bextract_kernel, dim3(grid_for(cols * n)), dim3(TPB), 0, st, t2, dst, steps, n, cols);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st) {
+  hipLaunchKernelGGL(stark_leaves_kernel, dim3(grid_for(a.n >> 2), a.batch), dim3(TPB), 0, st, a, d_nodes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return shk_merkle_upper_levels(a.n, a.batch, d_nodes, st);
+}
+
+hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
+                             fp* d_scal, hipStream_t st) {
+  hipLaunchKernelGGL(stark_scalars_kernel, dim3(batch), dim3(64), 0, st, d_mnodes, tree_words, width, cpow, d_scal);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_lincomb(const StarkArgs& a, const fp* d_scal, fp* d_l, hipStream_t st) {
+  hipLaunchKernelGGL(stark_lincomb_kernel, dim3(grid_for(a.n * a.batch)), dim3(TPB), 0, st, a, d_scal, d_l);
+  return hipGetLastError();
+}
+
+hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const uint32_t* d_ys,
+                            uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st) {
+  uint32_t lg = 0;
+  while ((1ull << lg) < a.n) ++lg;
+  const uint32_t k = 3 * a.width;
+  const uint64_t per_proof = 2 + (uint64_t)samples * (2 * (2 * k + (lg - 1)) + (lg + 1));
+  hipLaunchKernelGGL(stark_gather_kernel, dim3(grid_for(per_proof * a.batch)), dim3(TPB), 0, st, a, d_mnodes, d_lnodes, d_ys,
+                     samples, lg, d_proof, stride);
+  return hipGetLastError();
+}

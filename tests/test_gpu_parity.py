@@ -567,3 +567,133 @@ def test_degenerate_inputs(sa, oracle):
     from starks_amd.polynomial import polynomials_over
     zero = polynomials_over(sa.F).factory([0, 0, 0])
     assert zero.coefficients == [] and [int(v) for v in sa.fft.NonBinaryFFT(sa.F, sa.F(root_of(16))).fft(zero)] == [0] * 16
+
+
+# ---- STARK.mk_proof (stark.py:233-279): SURVEY 8(f) rank 4 ---------------------------------------------------
+def _stark_setup(sa, c):
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import multivariates_over
+    mv = multivariates_over(sa.F, c["width"]).factory
+    polys = [mv({tuple(k): v for k, v in d}) for d in c["step_polys"]]
+    witness = [[h2i(x) for x in col] for col in c["witness"]]
+    return stark, polys, witness
+
+
+@pytest.mark.parametrize("c", load_golden("stark.json"), ids=lambda c: c["name"])
+def test_stark_proofs_golden(sa, oracle, c):
+    """The reference's own mk_proof output (run live by tests/golden/generate.py), byte for byte."""
+    stark, polys, witness = _stark_setup(sa, c)
+    flat = stark.prove_flat(b"".join(wire(col) for col in witness), wire(c["inputs"]), c["steps"], c["ext"], c["width"], polys)
+    assert len(flat) == c["flat_len"]
+    proof = stark.unpack_proof(flat, c["steps"], c["ext"], c["width"], c["degree"])
+    assert proof[0].hex() == c["m_root"], "m_root"
+    assert proof[1].hex() == c["l_root"], "l_root"
+    assert [b.hex() for b in proof[2][0]] == c["branch0"]
+    assert hashlib.sha256(flat).hexdigest() == c["flat_sha"]
+    path = os.path.join(GOLDEN, "stark_%s.flat.bin" % c["name"])
+    if os.path.exists(path):
+        assert flat == open(path, "rb").read()
+    # the drop-in call site, and both verifiers (the host mirror and the oracle's restatement)
+    S = stark.STARK(sa.F, c["steps"], c["ext"], c["width"], polys)
+    boundary = [(0, j, sa.F(v)) for j, v in enumerate(c["inputs"])]
+    pr = S.mk_proof([[sa.F(v) for v in col] for col in witness], boundary)
+    assert pr[0] == proof[0] and pr[1] == proof[1] and pr[2] == proof[2] and pr[3] == proof[3]
+    assert S.verify_proof(pr, witness, boundary)
+    sp = [{tuple(k): v for k, v in d} for d in c["step_polys"]]
+    assert oracle.py.verify_stark_proof(pr, [col[-1] for col in witness], c["inputs"], sp, c["steps"], c["ext"])
+
+
+def test_stark_random_vs_oracle(sa, oracle):
+    """Random sparse step polynomials, widths 1..4: flat proof == the oracle's coefficient-form prover."""
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import multivariates_over
+    po = oracle.py
+    rng = random.Random(77)
+    for width, steps, maxdeg in [(1, 8, 3), (2, 16, 2), (3, 16, 3), (4, 32, 2), (2, 64, 5), (5, 8, 2), (9, 8, 1)]:
+        sp = []
+        for _ in range(width):
+            terms = {}
+            for _ in range(rng.randint(1, 3)):
+                ex = [0] * width
+                for _ in range(rng.randint(0, maxdeg)):
+                    ex[rng.randrange(width)] += 1
+                terms[tuple(ex)] = rng.choice([1, 2, 3, rng.randrange(P), P - 1])
+            sp.append(terms)
+        inputs = [rng.randrange(P) for _ in range(width)]
+        w = po.get_computational_trace(inputs, steps, sp)
+        want = po.stark_flat(po.mk_stark_proof(w, inputs, sp, steps, 8))
+        mv = multivariates_over(sa.F, width).factory
+        got = stark.prove_flat(b"".join(wire(col) for col in w), wire(inputs), steps, 8, width, [mv(d) for d in sp])
+        assert got == want, (width, steps, sp)
+
+
+def test_stark_batch_and_invalid_witness(sa, oracle):
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    po = oracle.py
+    X1, X2 = generate_Xi_s(sa.F, 2)
+    polys = [X1, X1 + X2**3]
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    steps, ext = 32, 8
+    ws, ins = [], []
+    for j in range(3):
+        inp = [2 + j, 5 + 7 * j]
+        ws.append(po.get_computational_trace(inp, steps, sp))
+        ins.append(inp)
+    one = [stark.prove_flat(b"".join(wire(c) for c in w), wire(i), steps, ext, 2, polys) for w, i in zip(ws, ins)]
+    many = stark.prove_flat(b"".join(b"".join(wire(c) for c in w) for w in ws), b"".join(wire(i) for i in ins), steps, ext, 2,
+                            polys, batch=3)
+    assert many == b"".join(one)
+    assert one[1] == po.stark_flat(po.mk_stark_proof(ws[1], ins[1], sp, steps, ext))
+    # a witness that breaks one transition: the reference asserts `cp % z == 0` (stark.py:76)
+    bad = [list(c) for c in ws[0]]
+    bad[1][5] = (bad[1][5] + 1) % P
+    S = stark.STARK(sa.F, steps, ext, 2, polys)
+    boundary = [(0, j, v) for j, v in enumerate(ins[0])]
+    with pytest.raises(AssertionError):
+        S.mk_proof(bad, boundary)
+    # ... and the context is usable afterwards
+    pr = S.mk_proof(ws[0], boundary)
+    assert S.verify_proof(pr, ws[0], boundary)
+    # a tampered proof is rejected by the host verifier
+    leaf = bytearray(pr[2][0][0])
+    leaf[5] ^= 1
+    pr[2][0][0] = bytes(leaf)
+    with pytest.raises(AssertionError):
+        S.verify_proof(pr, ws[0], boundary)
+
+
+def test_stark_shape_errors(sa):
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    X = generate_Xi_s(sa.F, 1)[0]
+    assert stark.proof_len(8, 8, 10, 1) == 0           # width >= 10: get_pseudorandom_ks returns None (stark.py:106-126)
+    assert stark.proof_len(8, 8, 1, 9) == 0            # degree * (steps - 1) + 1 must stay below the domain
+    assert stark.proof_len(12, 8, 1, 1) == 0           # steps must be a power of two
+    assert stark.proof_len(8, 1, 1, 1) == 0            # exclude_multiples_of = 1 divides by zero (utils.py:90)
+    with pytest.raises(NotImplementedError):
+        stark.prove_flat(wire([1] * 8), wire([1]), 8, 8, 1, [X**9])
+
+
+@pytest.mark.parametrize("logsteps", [10, 14])
+def test_stark_large_prove_then_verify(sa, oracle, logsteps):
+    """Sizes the coefficient-form oracle cannot reach: prove on the device, verify with the host verifier and with the
+    oracle's restated verifier (transition + boundary identities at 80 positions, FRI on the linear combination)."""
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    steps, ext = 1 << logsteps, 8
+    X1, X2 = generate_Xi_s(sa.F, 2)
+    polys = [X1, X1 + X2**3]
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    inputs = [42, 3]
+    w = oracle.py.get_computational_trace(inputs, steps, sp)
+    S = stark.STARK(sa.F, steps, ext, 2, polys)
+    boundary = [(0, j, v) for j, v in enumerate(inputs)]
+    pr = S.mk_proof(w, boundary)
+    assert S.verify_proof(pr, w, boundary)
+    assert oracle.py.verify_stark_proof(pr, [c[-1] for c in w], inputs, sp, steps, ext)
+    # the P evaluations inside the leaves are the low-degree extension of the witness
+    pos = sa.utils.get_pseudorandom_indices(pr[1], steps * ext, 80, exclude_multiples_of=ext)[0]
+    leaf = sa.mt.unpack_merkle_leaf(pr[2][0][0], 2, 3)
+    lde = oracle.c.lde_bytes(wire(w[1]), ext, root_of(steps * ext))
+    assert leaf[1] == lde[32 * pos:32 * pos + 32]
