@@ -144,6 +144,43 @@ def extras(dev, quick):
                                                    "algorithmic_GBps": 203.0 * n / ms / 1e6}
         dev.free(dc)
         dev.free(dp)
+    # ---- whole prover: STARK.mk_proof (stark.py:233-279) for the reference's MiMC formulation, width 2 ------------
+    # step polynomials [X_1, X_1 + X_2^3] (test_stark.py:265-293); config 5's unit of work is one such proof
+    from starks_amd import stark as _stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    from starks_amd.modp import IntegersModP
+    X1, X2 = generate_Xi_s(IntegersModP(P), 2)
+    coefs, exps, counts, degree = _stark.pack_step_polys([X1, X1 + X2**3], 2)
+    for logsteps, bsz in ([(12, 4)] if quick else [(14, 1), (16, 1), (16, 32), (20, 1)]):
+        steps, ext, width = 1 << logsteps, 8, 2
+        k, x = 42, 3
+        col = [x]
+        for _ in range(steps - 1):
+            x = (x * x * x + k) % P
+            col.append(x)
+        wit = b"".join(v.to_bytes(32, "big") for v in [k] * steps + col) * bsz
+        inp = (k.to_bytes(32, "big") + (3).to_bytes(32, "big")) * bsz
+        plen = _stark.proof_len(steps, ext, width, degree)
+        dw, di, dp = dev.alloc(len(wit)), dev.alloc(len(inp)), dev.alloc(plen * bsz)
+        dev.ck(L.sh_dev_from_wire(ctx, inp, di, width * bsz), "inputs")
+        best = None
+        for _ in range(4):  # the prover consumes its witness: re-upload (untimed) before every timed call
+            dev.ck(L.sh_dev_from_wire(ctx, wit, dw, width * steps * bsz), "witness")
+            dev.sync()
+            dev.ck(L.sh_timer_start(ctx), "timer")
+            dev.ck(L.sh_dev_stark_prove(ctx, dw, di, steps, ext, width, coefs, exps, counts, 80, bsz, dp), "stark")
+            t = ctypes.c_float()
+            dev.ck(L.sh_timer_stop(ctx, ctypes.byref(t)), "timer")
+            best = t.value if best is None else min(best, t.value)
+        dev.ck(L.sh_stark_status(ctx), "stark status")
+        head = ctypes.create_string_buffer(64)
+        dev.ck(L.sh_dev_download(ctx, dp, head, 64), "dl")
+        out["stark_prove_batch%d_steps_2^%d" % (bsz, logsteps)] = {
+            "ms_per_batch": round(best, 4), "ms_per_proof": round(best / bsz, 5), "proofs_per_s": bsz / best * 1e3,
+            "proof_bytes": plen, "m_root": head.raw[:32].hex()}
+        dev.free(dw)
+        dev.free(di)
+        dev.free(dp)
     return out
 
 

@@ -56,5 +56,41 @@ def prove_mimc_batch(unit_ids, steps, ext=8, samples=40, chunk=16):
     return out
 
 
+def mimc_stark_unit(j, steps, constant=42):
+    """Unit j of the synthetic many-proof workload as a full STARK: the reference's MiMC formulation of
+    test_stark.py:265-293 -- width 2, step polynomials [X_1, X_1 + X_2^3], i.e. x <- x^3 + k with the round constant k
+    carried in dimension 1 -- started from (k, 3 + j).  Returns (witness[dim][step], inputs)."""
+    x = (3 + j) % MIMC_P
+    col = [x]
+    for _ in range(steps - 1):
+        x = (x * x * x + constant) % MIMC_P
+        col.append(x)
+    return [[constant] * steps, col], [constant, (3 + j) % MIMC_P]
+
+
+def prove_stark_batch(unit_ids, steps, ext=8, chunk=16):
+    """Full STARK proofs (STARK.mk_proof, stark.py:233-279) of the units `mimc_stark_unit(j)`, `chunk` proofs per
+    batched launch.  Returns [(j, flat_proof_bytes)] (layout: include/starkhip.h).  Runs on this process's GPU."""
+    from . import stark
+    from .modp import IntegersModP
+    from .multivariate_polynomial import generate_Xi_s
+    X1, X2 = generate_Xi_s(IntegersModP(MIMC_P), 2)
+    polys = [X1, X1 + X2**3]
+    plen = stark.proof_len(steps, ext, 2, 3)
+    out = []
+    ids = list(unit_ids)
+    for c in range(0, len(ids), chunk):
+        part = ids[c:c + chunk]
+        wit, inp = bytearray(), bytearray()
+        for j in part:
+            w, i = mimc_stark_unit(j, steps)
+            for col in w:
+                wit += b"".join(v.to_bytes(32, "big") for v in col)
+            inp += b"".join(v.to_bytes(32, "big") for v in i)
+        flat = stark.prove_flat(bytes(wit), bytes(inp), steps, ext, 2, polys, batch=len(part))
+        out.extend((j, flat[i * plen:(i + 1) * plen]) for i, j in enumerate(part))
+    return out
+
+
 def digest(proof_bytes):
     return hashlib.sha256(proof_bytes).digest()

@@ -697,3 +697,45 @@ def test_stark_large_prove_then_verify(sa, oracle, logsteps):
     leaf = sa.mt.unpack_merkle_leaf(pr[2][0][0], 2, 3)
     lde = oracle.c.lde_bytes(wire(w[1]), ext, root_of(steps * ext))
     assert leaf[1] == lde[32 * pos:32 * pos + 32]
+
+
+def test_stark_batch_units_and_device_api(sa, oracle):
+    """batch.prove_stark_batch (config 5's unit as a full STARK) == the oracle per unit; and the device-resident entry
+    point with its deferred constraint status."""
+    import ctypes
+    from starks_amd import batch, stark
+    po = oracle.py
+    steps, ext = 64, 8
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    got = batch.prove_stark_batch([0, 5, 9], steps, ext, chunk=2)
+    for j, flat in got:
+        w, inp = batch.mimc_stark_unit(j, steps)
+        assert w == po.get_computational_trace(inp, steps, sp)
+        assert flat == po.stark_flat(po.mk_stark_proof(w, inp, sp, steps, ext)), j
+    # device-resident: same bytes; a broken witness is reported by sh_stark_status, once
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    X1, X2 = generate_Xi_s(sa.F, 2)
+    coefs, exps, counts, degree = stark.pack_step_polys([X1, X1 + X2**3], 2)
+    plen = stark.proof_len(steps, ext, 2, degree)
+    w, inp = batch.mimc_stark_unit(5, steps)
+
+    def dev_prove(cols):
+        dw, di, dp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        for ptr, nbytes in ((dw, 64 * steps), (di, 64), (dp, plen)):
+            sa.lib.check(L.sh_dev_alloc(ctx, nbytes, ctypes.byref(ptr)), "alloc")
+        sa.lib.check(L.sh_dev_from_wire(ctx, b"".join(wire(c) for c in cols), dw, 2 * steps), "w")
+        sa.lib.check(L.sh_dev_from_wire(ctx, wire(inp), di, 2), "i")
+        sa.lib.check(L.sh_dev_stark_prove(ctx, dw, di, steps, ext, 2, coefs, exps, counts, 80, 1, dp), "prove")
+        out = ctypes.create_string_buffer(plen)
+        sa.lib.check(L.sh_dev_download(ctx, dp, out, plen), "dl")
+        for ptr in (dw, di, dp):
+            sa.lib.check(L.sh_dev_free(ctx, ptr), "free")
+        return out.raw
+    assert dev_prove(w) == dict(got)[5]
+    assert L.sh_stark_status(ctx) == 0
+    bad = [list(c) for c in w]
+    bad[1][-1] = (bad[1][-1] + 1) % P  # breaks the last transition only
+    dev_prove(bad)
+    assert L.sh_stark_status(ctx) == -8
+    assert L.sh_stark_status(ctx) == 0
