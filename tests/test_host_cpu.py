@@ -122,3 +122,42 @@ def test_stark_helpers_restated_from_text():
         assert verify_branch(m[1], p, br[3 * k], output_as_int=True) == p * 7 + 1
         assert verify_branch(m[1], (p + ext) % n, br[3 * k + 1], output_as_int=True) == ((p + ext) % n) * 7 + 1
         assert verify_branch(lt[1], p, br[3 * k + 2], output_as_int=True) == p * 11 + 3
+
+
+def test_stark_host_mirror_on_reference_proofs():
+    """The host side of STARK (step-polynomial type, witness helpers, proof unpacking, verifier) against the proofs of
+    the live reference (tests/golden/stark.json via the oracle, which test_oracle_golden pins byte for byte)."""
+    _build()
+    import hashlib
+    from oracle import pyoracle as po
+    from starks_amd import IntegersModP, stark
+    from starks_amd.air import AIR
+    from starks_amd.multivariate_polynomial import multivariates_over, generate_Xi_s
+    F = IntegersModP(P)
+    X1, X2 = generate_Xi_s(F, 2)
+    assert (X1 + X2**3).coefficients == {(1, 0): 1, (0, 3): 1} and (X1 + X2**3).degree() == 3
+    assert (3 * X2 + F(2) * X1 - 1).coefficients == {(0, 1): 3, (1, 0): 2, (0, 0): P - 1}
+    assert (X1 * X2 - X2 * X1).is_zero() and int((X1 + X2**3)([F(2), 5])) == 127
+    for c in load_golden("stark.json"):
+        mv = multivariates_over(F, c["width"]).factory
+        polys = [mv({tuple(k): v for k, v in d}) for d in c["step_polys"]]
+        sp = [{tuple(k): v for k, v in d} for d in c["step_polys"]]
+        air = AIR(F, c["width"], c["inputs"], c["steps"], polys, c["ext"])
+        witness = air.generate_witness()
+        assert [[int(v) for v in col] for col in witness] == [[int(x, 16) for x in col] for col in c["witness"]]
+        boundary = air.generate_boundary_constraints()
+        assert [(b[0], b[1], int(b[2])) for b in boundary] == [(0, j, v % P) for j, v in enumerate(c["inputs"])]
+        S = stark.STARK(F, c["steps"], c["ext"], c["width"], polys)
+        assert S.get_degree() == c["degree"] == stark.pack_step_polys(polys, c["width"])[3]
+        ref = po.mk_stark_proof([[int(v) for v in col] for col in witness], c["inputs"], sp, c["steps"], c["ext"])
+        flat = po.stark_flat(ref)
+        assert hashlib.sha256(flat).hexdigest() == c["flat_sha"]
+        assert stark.proof_len(c["steps"], c["ext"], c["width"], c["degree"]) == len(flat)   # host-only C entry point
+        assert stark.unpack_proof(flat, c["steps"], c["ext"], c["width"], c["degree"]) == ref
+        assert S.verify_proof(ref, witness, boundary)
+        bad = [ref[0], ref[1], [list(b) for b in ref[2]], ref[3]]
+        leaf = bytearray(bad[2][0][0])
+        leaf[40] ^= 1
+        bad[2][0][0] = bytes(leaf)
+        with pytest.raises(AssertionError):
+            S.verify_proof(bad, witness, boundary)
