@@ -102,10 +102,12 @@ struct sh_ctx {
   uint8_t* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
-  // STARK prover state: NTT_2s(Z3) per (steps, ext); the step-polynomial terms last uploaded; the constraint flag
-  std::map<std::pair<uint64_t, uint32_t>, void*> z3hat;
+  // STARK prover state: 1/(x_i - 1) per domain size; 1/(omega^j - 1) per (steps, ext); the step-polynomial terms last
+  // uploaded (and their partial derivatives); the constraint flag
+  std::map<uint64_t, void*> inv_xm1;
+  std::map<std::pair<uint64_t, uint32_t>, void*> inv_omega;
   std::vector<uint8_t> terms_key;
-  void* terms_dev = nullptr;
+  void* terms_dev = nullptr;   // [terms][derivative terms]: see TermLayout
   uint32_t terms_begin[SHK_STARK_MAX_WIDTH + 1] = {};
   uint32_t terms_degree = 0;
   uint32_t* bad_flag = nullptr;
@@ -532,12 +534,23 @@ int stark_check_shape(uint64_t steps, uint32_t ext, uint32_t width, uint32_t deg
   return fri_validate(steps * ext, steps * degree, ext, 40);
 }
 
-// Parse + upload the step polynomials' terms (skipped when they equal the previous call's).
+// Device layout of the step-polynomial description (one allocation, ctx->terms_dev)
+struct TermLayout {
+  static constexpr size_t MAXT = SHK_STARK_MAX_TERMS, MAXD = SHK_STARK_MAX_TERMS * SHK_STARK_MAX_WIDTH;
+  static constexpr size_t coef = 0;                                  // fp[MAXT]
+  static constexpr size_t dcoef = coef + MAXT * sizeof(fp);          // fp[MAXD]
+  static constexpr size_t exps = dcoef + MAXD * sizeof(fp);          // u8[MAXT][W]
+  static constexpr size_t dexps = exps + MAXT * SHK_STARK_MAX_WIDTH; // u8[MAXD][W]
+  static constexpr size_t dbegin = dexps + MAXD * SHK_STARK_MAX_WIDTH;  // u32[W * W + 1]
+  static constexpr size_t total = dbegin + 4 * (SHK_STARK_MAX_WIDTH * SHK_STARK_MAX_WIDTH + 1);
+};
+
+// Parse + upload the step polynomials' terms and their partial derivatives (skipped when equal to the previous call's).
 int stark_terms(sh_ctx* c, uint32_t width, const uint8_t* coefs, const uint8_t* exps, const uint32_t* counts) {
   if (!coefs || !exps || !counts) return SH_ERR_INVALID;
   uint64_t total = 0;
   for (uint32_t d = 0; d < width; ++d) total += counts[d];
-  if (total == 0 || total > 256) return total ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
+  if (total == 0 || total > SHK_STARK_MAX_TERMS) return total ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
   std::vector<uint8_t> key;
   key.push_back((uint8_t)width);
   key.insert(key.end(), reinterpret_cast<const uint8_t*>(counts), reinterpret_cast<const uint8_t*>(counts + width));
@@ -550,16 +563,36 @@ int stark_terms(sh_ctx* c, uint32_t width, const uint8_t* coefs, const uint8_t* 
     for (uint32_t v = 0; v < width; ++v) sum += exps[t * width + v];
     if (sum > degree) degree = sum;  // MultivariatePolynomial.degree (multivariate_polynomial.py:111-117)
   }
-  std::vector<fp> lim(total);
-  for (uint64_t t = 0; t < total; ++t) lim[t] = h_from_wire(coefs + 32 * t);
-  constexpr size_t CAP = 256 * sizeof(fp) + 256 * SHK_STARK_MAX_WIDTH;
+  std::vector<uint8_t> img(TermLayout::total, 0);
+  fp* cf = reinterpret_cast<fp*>(img.data() + TermLayout::coef);
+  fp* dcf = reinterpret_cast<fp*>(img.data() + TermLayout::dcoef);
+  uint8_t* ex = img.data() + TermLayout::exps;
+  uint8_t* dex = img.data() + TermLayout::dexps;
+  uint32_t* dbeg = reinterpret_cast<uint32_t*>(img.data() + TermLayout::dbegin);
+  for (uint64_t t = 0; t < total; ++t) cf[t] = h_from_wire(coefs + 32 * t);
+  memcpy(ex, exps, (size_t)width * total);
+  // d/dX_v of coef * prod X^e = (coef * e_v) * X_v^(e_v - 1) * prod_{u != v} X_u^e_u
+  uint32_t begin[SHK_STARK_MAX_WIDTH + 1] = {0};
+  for (uint32_t d = 0; d < width; ++d) begin[d + 1] = begin[d] + counts[d];
+  uint32_t nd = 0;
+  for (uint32_t d = 0; d < width; ++d) {
+    for (uint32_t v = 0; v < width; ++v) {
+      dbeg[d * width + v] = nd;
+      for (uint32_t t = begin[d]; t < begin[d + 1]; ++t) {
+        const uint32_t e = exps[(size_t)t * width + v];
+        if (!e) continue;
+        dcf[nd] = fp_mul(cf[t], fp_from_u32(e));
+        memcpy(dex + (size_t)nd * width, exps + (size_t)t * width, width);
+        dex[(size_t)nd * width + v] = (uint8_t)(e - 1);
+        ++nd;
+      }
+    }
+  }
+  dbeg[width * width] = nd;
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // earlier launches may still read the old terms
-  if (!c->terms_dev) HIP_TRY(c, hipMalloc(&c->terms_dev, CAP));
-  HIP_TRY(c, hipMemcpy(c->terms_dev, lim.data(), total * sizeof(fp), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(reinterpret_cast<uint8_t*>(c->terms_dev) + 256 * sizeof(fp), exps, (size_t)width * total,
-                       hipMemcpyHostToDevice));
-  c->terms_begin[0] = 0;
-  for (uint32_t d = 0; d < width; ++d) c->terms_begin[d + 1] = c->terms_begin[d] + counts[d];
+  if (!c->terms_dev) HIP_TRY(c, hipMalloc(&c->terms_dev, TermLayout::total));
+  HIP_TRY(c, hipMemcpy(c->terms_dev, img.data(), TermLayout::total, hipMemcpyHostToDevice));
+  memcpy(c->terms_begin, begin, sizeof begin);
   c->terms_degree = degree;
   c->terms_key.swap(key);
   return SH_OK;
@@ -573,25 +606,23 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   const uint64_t n = steps * ext, cols = (uint64_t)batch * width;
   if (cols > 0xffffffffull) return SH_ERR_UNSUPPORTED;
   const fp g2 = h_root_of_order_pow2(ilog2(n));           // stark.py:205
-  uint8_t g2b[32], g1b[32], hb[32];
+  uint8_t g2b[32], g1b[32];
   h_to_wire(g2, g2b);
   h_to_wire(h_pow(g2, ext), g1b);                          // G1 = G2^ext (stark.py:208)
-  h_to_wire(h_pow(g2, ext / 2), hb);                       // order 2 steps: the domain of the boundary product
-  NttPlan *fwd_n, *inv_n, *inv_s, *fwd_2s, *inv_2s;
+  NttPlan *fwd_n, *inv_s, *fwd_s;
   SH_TRY(plan_for(c, g2b, n, false, &fwd_n));
-  SH_TRY(plan_for(c, g2b, n, true, &inv_n));
   SH_TRY(plan_for(c, g1b, steps, true, &inv_s));
-  SH_TRY(plan_for(c, hb, 2 * steps, false, &fwd_2s));
-  SH_TRY(plan_for(c, hb, 2 * steps, true, &inv_2s));
+  SH_TRY(plan_for(c, g1b, steps, false, &fwd_s));
+  const fp g1 = h_pow(g2, ext);
   const fp x_last = h_pow(g2, (steps - 1) * ext);          // stark.py:212
   const fp inv_last_m1 = h_inv(fp_sub(x_last, fp_one()));
   const fp cpow = h_pow(h_pow(g2, steps), n - 1);          // `powers[i]` after the loop: (G2^steps)^(precision-1) (stark.py:150-158)
 
-  void *pe, *dw, *bw, *t2, *small, *mt;
+  void *pe, *dw, *bw, *qv, *small, *mt;
   SH_TRY(ws_get(c, sh_ctx::WS_ST_P, cols * n * sizeof(fp), &pe));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_D, cols * n * sizeof(fp), &dw));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_B, cols * n * sizeof(fp), &bw));
-  SH_TRY(ws_get(c, sh_ctx::WS_ST_T2, cols * 2 * steps * sizeof(fp), &t2));
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_T2, cols * steps * sizeof(fp), &qv));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_MTREE, (size_t)batch * 2 * n * 32, &mt));
   const size_t iab_bytes = cols * 2 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp);
   SH_TRY(ws_get(c, sh_ctx::WS_ST_SMALL, iab_bytes + scal_bytes + (size_t)batch * samples * 4, &small));
@@ -602,39 +633,72 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bad_flag), 64));
     HIP_TRY(c, hipMemsetAsync(c->bad_flag, 0, 64, c->stream));
   }
-  // Z3's transform over the 2 steps domain, once per (steps, ext)
-  fp* z3 = nullptr;
+  // cached inverses: 1 / (x_i - 1) over the domain, 1 / (omega^j - 1) for the ext-th roots of unity omega^j = x^steps
+  fp* inv_xm1 = nullptr;
   {
-    const auto key = std::make_pair(steps, ext);
-    auto it = c->z3hat.find(key);
-    if (it == c->z3hat.end()) {
-      void* z = nullptr;
-      HIP_TRY(c, hipMalloc(&z, 2 * steps * sizeof(fp)));
-      c->z3hat[key] = z;
-      z3 = reinterpret_cast<fp*>(z);
-      HIP_TRY(c, shk_stark_z3(z3, steps, ext, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, fp_neg(inv_last_m1), c->stream));
-      SH_TRY(run_ntt(c, fwd_2s, z3, z3, 1));
+    auto it = c->inv_xm1.find(n);
+    if (it == c->inv_xm1.end()) {
+      void* t = nullptr;
+      HIP_TRY(c, hipMalloc(&t, n * sizeof(fp)));
+      c->inv_xm1[n] = t;
+      inv_xm1 = reinterpret_cast<fp*>(t);
+      HIP_TRY(c, shk_stark_inv_xm1(inv_xm1, n, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, c->stream));
     } else {
-      z3 = reinterpret_cast<fp*>(it->second);
+      inv_xm1 = reinterpret_cast<fp*>(it->second);
     }
   }
+  fp* inv_omega = nullptr;
+  {
+    const auto key = std::make_pair(steps, ext);
+    auto it = c->inv_omega.find(key);
+    if (it == c->inv_omega.end()) {
+      std::vector<fp> host(ext, fp_zero());
+      const fp omega = h_pow(g2, steps);
+      fp w = omega;
+      for (uint32_t j = 1; j < ext; ++j) {
+        host[j] = h_inv(fp_sub(w, fp_one()));
+        w = fp_mul(w, omega);
+      }
+      void* t = nullptr;
+      HIP_TRY(c, hipMalloc(&t, ext * sizeof(fp)));
+      c->inv_omega[key] = t;
+      HIP_TRY(c, hipMemcpy(t, host.data(), ext * sizeof(fp), hipMemcpyHostToDevice));
+      inv_omega = reinterpret_cast<fp*>(t);
+    } else {
+      inv_omega = reinterpret_cast<fp*>(it->second);
+    }
+  }
+  const uint8_t* tb = reinterpret_cast<const uint8_t*>(c->terms_dev);
   StarkArgs a;
   memset(&a, 0, sizeof a);
   a.p_evals = reinterpret_cast<fp*>(pe);
   a.d_work = reinterpret_cast<fp*>(dw);
   a.b_work = reinterpret_cast<fp*>(bw);
+  a.q_evals = reinterpret_cast<fp*>(qv);
+  a.iab = iab;
   a.n = n;
+  a.steps = steps;
   a.ext = ext;
   a.width = width;
   a.batch = batch;
   a.tw_lo = fwd_n->base.lo;
   a.tw_hi = fwd_n->base.hi;
   a.tw_lb = fwd_n->base.lb;
+  a.inv_xm1 = inv_xm1;
+  a.inv_omega = inv_omega;
   a.x_last = x_last;
-  a.term_coef = reinterpret_cast<const fp*>(c->terms_dev);
-  a.term_exps = reinterpret_cast<const uint8_t*>(c->terms_dev) + 256 * sizeof(fp);
+  a.g1 = g1;
+  a.inv_steps = h_pow(h_inv(fp_from_u32(2u)), (uint64_t)ilog2(steps));
+  a.inv_1_m_last = fp_neg(inv_last_m1);
+  a.bad = c->bad_flag;
+  a.term_coef = reinterpret_cast<const fp*>(tb + TermLayout::coef);
+  a.term_exps = tb + TermLayout::exps;
   memcpy(a.term_begin, c->terms_begin, sizeof a.term_begin);
+  a.dterm_coef = reinterpret_cast<const fp*>(tb + TermLayout::dcoef);
+  a.dterm_exps = tb + TermLayout::dexps;
+  a.dterm_begin = reinterpret_cast<const uint32_t*>(tb + TermLayout::dbegin);
   fp* P = reinterpret_cast<fp*>(pe);
+  fp* Q = reinterpret_cast<fp*>(qv);
 
   // boundary interpolants need witness[dim][-1] before the trace becomes coefficients (stark.py:91-96)
   HIP_TRY(c, shk_stark_interp(d_wit, d_inputs, steps, (uint32_t)cols, inv_last_m1, iab, c->stream));
@@ -642,19 +706,11 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   SH_TRY(run_ntt(c, inv_s, d_wit, d_wit, (uint32_t)cols));
   HIP_TRY(c, shk_pad_copy(d_wit, P, steps, n, (uint32_t)cols, c->stream));
   SH_TRY(run_ntt(c, fwd_n, P, P, (uint32_t)cols));
-  // D = C / Z (stark.py:38-79): C (X - x_last) pointwise, coefficients, divide by X^steps - 1, evaluate
-  HIP_TRY(c, shk_stark_constraints(a, c->stream));
-  SH_TRY(run_ntt(c, inv_n, a.d_work, a.d_work, (uint32_t)cols));
-  HIP_TRY(c, shk_stark_divide(a.d_work, steps, ext, cols, c->bad_flag, c->stream));
-  SH_TRY(run_ntt(c, fwd_n, a.d_work, a.d_work, (uint32_t)cols));
-  // B = (P - I) / Z2 (stark.py:81-104): (P - I) Z3 over the 2 steps domain, upper half, evaluate
-  fp* T2 = reinterpret_cast<fp*>(t2);
-  HIP_TRY(c, shk_stark_bprep(d_wit, iab, T2, steps, cols, c->stream));
-  SH_TRY(run_ntt(c, fwd_2s, T2, T2, (uint32_t)cols));
-  HIP_TRY(c, shk_mul_bcast(T2, z3, 2 * steps, cols, c->stream));
-  SH_TRY(run_ntt(c, inv_2s, T2, T2, (uint32_t)cols));
-  HIP_TRY(c, shk_stark_bextract(T2, a.b_work, steps, n, cols, c->stream));
-  SH_TRY(run_ntt(c, fwd_n, a.b_work, a.b_work, (uint32_t)cols));
+  // Q = X P'(X) on the trace points, for the quotients' values there
+  HIP_TRY(c, shk_stark_qprep(d_wit, Q, steps, cols, c->stream));
+  SH_TRY(run_ntt(c, fwd_s, Q, Q, (uint32_t)cols));
+  // D = C / Z and B = (P - I) / Z2 (stark.py:38-104), evaluated on the whole domain
+  HIP_TRY(c, shk_stark_quotients(a, c->stream));
   // mtree = merkelize_polynomial_evaluations(width, P + D + B evaluations) (stark.py:257)
   uint32_t* mtree = reinterpret_cast<uint32_t*>(mt);
   HIP_TRY(c, shk_stark_merkelize(a, mtree, c->stream));
@@ -726,7 +782,8 @@ void sh_ctx_destroy(sh_ctx* c) {
   }
   for (int i = 0; i < sh_ctx::WS_COUNT; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
-  for (auto& kv : c->z3hat) (void)hipFree(kv.second);
+  for (auto& kv : c->inv_xm1) (void)hipFree(kv.second);
+  for (auto& kv : c->inv_omega) (void)hipFree(kv.second);
   if (c->terms_dev) (void)hipFree(c->terms_dev);
   if (c->bad_flag) (void)hipFree(c->bad_flag);
   for (int i = 0; i < 2; ++i) {

@@ -251,6 +251,19 @@ FP_HD fp fp_pow_u64(fp a, uint64_t e) {
   return r;
 }
 
+// a^-1 = a^(p-2) (modp.py:71-79 uses extended Euclid; the residue is the same).  0 -> 0.
+FP_HD fp fp_inv(const fp& a) {
+  fp r = fp_one(), b = a;
+#pragma unroll 1
+  for (int i = 0; i < 256; ++i) {
+    // p - 2 = 2^256 - 351 * 2^32 - 1: limb 0 = 0xffffffff, limb 1 = 0xfffffea0, limbs 2..7 = 0xffffffff
+    const uint32_t limb = (i >> 5) == 1 ? 0xfffffea0u : 0xffffffffu;
+    if ((limb >> (i & 31)) & 1u) r = fp_mul(r, b);
+    b = fp_sqr(b);
+  }
+  return r;
+}
+
 // ---- wire form <-> limb form ------------------------------------------------------------------
 // Wire form = 32 bytes big-endian (modp.py:94-95).  Word k of the wire form read as a little-endian
 // u32 is bswap(limb[7-k]).

@@ -88,31 +88,42 @@ hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* 
 
 // ---- stark.hip: constraint / boundary quotients, packed tree, linear combination, spot checks (stark.py:233-279) ----
 constexpr uint32_t SHK_STARK_MAX_WIDTH = 9;  // get_pseudorandom_ks returns None from 10 on (stark.py:106-126)
+constexpr uint32_t SHK_STARK_MAX_TERMS = 256;
 struct StarkArgs {
   const fp* p_evals;  // [batch * width][n]  trace polynomials on the G2 domain
-  fp* d_work;         // [batch * width][n]  C (X - x_last) evaluations -> coefficients -> D coefficients -> D evaluations
-  fp* b_work;         // [batch * width][n]  B coefficients -> B evaluations
+  fp* d_work;         // [batch * width][n]  D evaluations
+  fp* b_work;         // [batch * width][n]  B evaluations
+  const fp* q_evals;  // [batch * width][steps]  Q_c = X P_c'(X) on G1
+  const fp* iab;      // [batch * width][2]  boundary interpolant a + b X
   uint64_t n;         // precision = steps * ext
+  uint64_t steps;
   uint32_t ext;
   uint32_t width;
   uint32_t batch;
   const fp* tw_lo;    // powers of G2: G2^e = lo[e & mask] (* hi[e >> lb] when hi)
   const fp* tw_hi;
   uint32_t tw_lb;
+  const fp* inv_xm1;    // [n]   1 / (x_i - 1), entry 0 = 0
+  const fp* inv_omega;  // [ext] 1 / (omega^j - 1), omega = G2^steps, entry 0 = 0
   fp x_last;          // G2^((steps - 1) ext)  (stark.py:212)
-  const fp* term_coef;     // step polynomials: term t = coef[t] * prod_v X_v^exps[t][v]
+  fp g1;              // G2^ext = 1 / x_last
+  fp inv_steps;       // 1 / steps
+  fp inv_1_m_last;    // 1 / (1 - x_last)
+  uint32_t* bad;      // set to 1 when a transition constraint fails on the trace
+  // step polynomials: term t = coef[t] * prod_v X_v^exps[t][v]; terms of dimension c: [term_begin[c], term_begin[c+1])
+  const fp* term_coef;
   const uint8_t* term_exps;
-  uint32_t term_begin[SHK_STARK_MAX_WIDTH + 1];  // terms of dimension c: [term_begin[c], term_begin[c+1])
+  uint32_t term_begin[SHK_STARK_MAX_WIDTH + 1];
+  // their partial derivatives: d step_c / d X_v = terms [dterm_begin[c * width + v], dterm_begin[c * width + v + 1])
+  const fp* dterm_coef;
+  const uint8_t* dterm_exps;
+  const uint32_t* dterm_begin;
 };
 hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, uint32_t cols, const fp& inv_last_m1, fp* iab,
                             hipStream_t st);
-hipError_t shk_stark_constraints(const StarkArgs& a, hipStream_t st);
-hipError_t shk_stark_divide(fp* e, uint64_t steps, uint32_t ext, uint64_t cols, uint32_t* bad, hipStream_t st);
-hipError_t shk_stark_z3(fp* out, uint64_t steps, uint32_t ext, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb,
-                        const fp& inv_1_m_last, hipStream_t st);
-hipError_t shk_stark_bprep(const fp* pcoef, const fp* iab, fp* t2, uint64_t steps, uint64_t cols, hipStream_t st);
-hipError_t shk_mul_bcast(fp* a, const fp* b, uint64_t len, uint64_t cols, hipStream_t st);
-hipError_t shk_stark_bextract(const fp* t2, fp* dst, uint64_t steps, uint64_t n, uint64_t cols, hipStream_t st);
+hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols, hipStream_t st);
+hipError_t shk_stark_inv_xm1(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, hipStream_t st);
+hipError_t shk_stark_quotients(const StarkArgs& a, hipStream_t st);
 hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st);
 hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
                              fp* d_scal, hipStream_t st);

@@ -3,13 +3,19 @@
 // (P, D, B), the pseudorandom linear combination and the Merkle spot checks.
 //
 // The reference builds C = P(g1 X) - step(P), D = C / Z and B = (P - I) / Z2 in COEFFICIENT form with schoolbook
-// polynomial arithmetic (O(n^2), stark.py:38-104) and then evaluates them.  Here every product is pointwise on the
-// evaluation domain G2 (N = steps * ext points) and every division is by X^steps - 1, which is a stride-`steps`
-// recurrence on coefficients:
-//   D = C (X - x_last) / (X^steps - 1)             [Z  = (X^steps - 1) / (X - x_last),            stark.py:69-72]
-//   B = (P - I) Z3 / (X^steps - 1)                 [Z2 = (X - 1)(X - x_last), Z3 = (X^steps - 1) / Z2, stark.py:89]
-// with the exact polynomial quotients (not pointwise 0/0 at the trace points), so the committed evaluations and
-// therefore every Merkle root and proof byte equal the reference's.
+// polynomial arithmetic (O(n^2), stark.py:38-104) and then evaluates them on the N = steps * ext points x_i = G2^i.
+// Here D and B are evaluated directly, exactly, on that domain (s = steps, r = x_last = g1^-1, G1 = {x^s = 1}):
+//   Z  = (X^s - 1) / (X - r)         D(x) = C(x) (x - r) / (x^s - 1)
+//   Z2 = (X - 1)(X - r)              B(x) = (P(x) - I(x)) / ((x - 1)(x - r))
+// * off the trace points (i % ext != 0): x^s - 1 = omega^(i % ext) - 1 takes ext - 1 values (omega = G2^s), whose
+//   inverses are constants; 1 / (x_i - 1) is a per-domain table T, and 1 / (x_i - r) = g1 T[i + ext].
+// * on the trace points x in G1 the quotients are 0/0; the polynomial's value there is the formal-derivative limit
+//   (l'Hopital; exact in any field, s is invertible):  D(x) = C'(x) (x - r) x / s  for x != r,  D(r) = C(r) r / s,
+//   B(1) = (P'(1) - b) / (1 - r),  B(r) = (P'(r) - b) / (r - 1)   (I = a + b X).  With Q = X P'(X) (coefficients k p_k,
+//   one s-point NTT per column)  x C'(x) = Q_c(g1 x) - sum_v d step_c / d X_v (P(x)) Q_v(x).
+// C(x) = 0 on G1 minus {r} is the statement "the witness is a valid trace" (the reference asserts cp % z == 0,
+// stark.py:76); it is checked there directly.  Every value is the exact residue of the reference's polynomial at that
+// point, so every Merkle root and proof byte is identical.
 #include <stdlib.h>
 
 #include "blake2s.cuh"
@@ -54,104 +60,122 @@ __global__ void __launch_bounds__(TPB) stark_interp_kernel(const fp* trace, cons
   fp_store(iab + 2 * c + 1, b);
 }
 
-// ---- transition constraints on the evaluation domain (stark.py:38-57) --------------------------------------
-// cz[c][i] = (P_c(g1 x_i) - step_c(P_1(x_i) .. P_W(x_i))) * (x_i - x_last),  x_i = G2^i,  P_c(g1 x_i) = P_c[x_(i+ext)].
-// step_c = sum over its terms of coef * prod_v X_v^exps[v] (multivariate_polynomial.py:329-338).
+// ---- step polynomials: sparse terms coef * prod_v X_v^exps[v] (multivariate_polynomial.py:329-338) -----------
 template <int W>
-__global__ void __launch_bounds__(TPB) stark_constraint_kernel(StarkArgs a) {
+__device__ __forceinline__ fp eval_terms(const fp* coef, const uint8_t* exps, uint32_t t0, uint32_t t1, const fp (&P)[W]) {
+  fp acc = fp_zero();
+  for (uint32_t t = t0; t < t1; ++t) {
+    fp prod = fp_load(coef + t);
+    const uint8_t* ex = exps + (uint64_t)t * W;
+#pragma unroll
+    for (int v = 0; v < W; ++v) {
+      const uint32_t e = ex[v];
+      for (uint32_t k = 0; k < e; ++k) prod = fp_mul(prod, P[v]);
+    }
+    acc = fp_add(acc, prod);
+  }
+  return acc;
+}
+
+// q[c][k] = k * p[c][k]: coefficients of Q_c = X P_c'(X)
+__global__ void __launch_bounds__(TPB) stark_qprep_kernel(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols) {
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= cols * steps) return;
+  const uint64_t k = g % steps;
+  fp_store(q + g, fp_mul(fp_load(pcoef + g), fp_from_u32((uint32_t)k)));
+}
+
+// T[i] = 1 / (x_i - 1), T[0] = 0.  Once per domain size (cached by the context).
+__global__ void __launch_bounds__(TPB) stark_inv_xm1_kernel(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi,
+                                                            uint32_t tw_lb) {
+  const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  fp_store(out + i, fp_inv(fp_sub(pow_lookup(tw_lo, tw_hi, tw_lb, i), fp_one())));  // fp_inv(0) = 0
+}
+
+// ---- D and B off the trace points; B on the trace points other than 1 and x_last ------------------------------
+template <int W>
+__global__ void __launch_bounds__(TPB) stark_quotients_kernel(StarkArgs a) {
   const uint64_t N = a.n;
   const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   if (g >= N * a.batch) return;
   const uint64_t b = g / N, i = g - b * N;
+  const uint32_t j = (uint32_t)i & (a.ext - 1);
+  const uint64_t inext = (i + a.ext) & (N - 1);
+  if (j == 0 && (i == 0 || inext == 0)) return;  // x = 1 and x = x_last: stark_trace_points_kernel
   const fp* pe = a.p_evals + b * W * N;
   fp P[W];
 #pragma unroll
   for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + i);
-  const fp xm = fp_sub(pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i), a.x_last);
-  const uint64_t inext = (i + a.ext) & (N - 1);
+  const fp x = pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i);
+  // 1 / ((x - 1)(x - r)) = T[i] * g1 * T[i + ext]      (x / r = x g1 = x_(i + ext))
+  const fp wz = fp_mul(fp_mul(fp_load(a.inv_xm1 + i), fp_load(a.inv_xm1 + inext)), a.g1);
+  fp f = fp_zero();
+  if (j) f = fp_mul(fp_sub(x, a.x_last), fp_load(a.inv_omega + j));  // (x - r) / (x^s - 1)
 #pragma unroll 1
   for (int c = 0; c < W; ++c) {
-    fp acc = fp_zero();
-    for (uint32_t t = a.term_begin[c]; t < a.term_begin[c + 1]; ++t) {
-      fp prod = fp_load(a.term_coef + t);
-      const uint8_t* ex = a.term_exps + (uint64_t)t * W;
-#pragma unroll
-      for (int v = 0; v < W; ++v) {
-        const uint32_t e = ex[v];
-        for (uint32_t k = 0; k < e; ++k) prod = fp_mul(prod, P[v]);
-      }
-      acc = fp_add(acc, prod);
+    const uint64_t col = (b * W + c) * N;
+    const fp pc = fp_load(pe + (uint64_t)c * N + i);
+    const fp interp = fp_add(fp_load(a.iab + 2 * (b * W + c)), fp_mul(fp_load(a.iab + 2 * (b * W + c) + 1), x));
+    fp_store(a.b_work + col + i, fp_mul(fp_sub(pc, interp), wz));
+    if (j) {  // the 1-in-ext lanes on trace points leave D to stark_trace_points_kernel
+      const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], P);
+      const fp nxt = fp_load(pe + (uint64_t)c * N + inext);
+      fp_store(a.d_work + col + i, fp_mul(fp_sub(nxt, acc), f));
     }
-    const fp nxt = fp_load(pe + (uint64_t)c * N + inext);
-    fp_store(a.d_work + (b * W + c) * N + i, fp_mul(fp_sub(nxt, acc), xm));
   }
 }
 
-// ---- exact division by X^steps - 1 on coefficients ---------------------------------------------------------
-// e = coefficients of E = Q (X^s - 1), N of them: q_k = e_(k+s) + q_(k+s), q_k = 0 for k >= N - s.  One thread per
-// (column, residue k mod s) walks its chain from the top; the remainder e_r + q_r must vanish, otherwise the
-// witness violates a transition constraint (the reference asserts `cp % z == 0`, stark.py:76) -> *bad = 1.
-__global__ void __launch_bounds__(TPB) stark_divide_kernel(fp* e, uint64_t steps, uint32_t ext, uint64_t cols, uint32_t* bad) {
+// ---- the trace points x_k = g1^k (domain index k * ext): D everywhere, B at x = 1 and x = x_last, and the check ----
+template <int W>
+__global__ void __launch_bounds__(TPB) stark_trace_points_kernel(StarkArgs a) {
+  const uint64_t N = a.n, s = a.steps;
   const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= cols * steps) return;
-  const uint64_t c = g / steps, r = g - c * steps;
-  fp* col = e + c * steps * ext;
-  fp qn = fp_zero();
-  fp en = fp_load(col + r + (uint64_t)(ext - 1) * steps);
-  fp_store(col + r + (uint64_t)(ext - 1) * steps, qn);
-  for (uint32_t m = ext - 1; m-- > 0;) {
-    const uint64_t k = r + (uint64_t)m * steps;
-    const fp ek = fp_load(col + k);
-    const fp qk = fp_add(en, qn);
-    fp_store(col + k, qk);
-    en = ek;
-    qn = qk;
-  }
-  const fp rem = fp_canon(fp_add(en, qn));
-  uint32_t nz = 0;
+  if (g >= s * a.batch) return;
+  const uint64_t b = g / s, k = g - b * s;
+  const uint64_t i = k * a.ext, knext = (k + 1) & (s - 1), inext = knext * a.ext;
+  const fp* pe = a.p_evals + b * W * N;
+  const fp* qe = a.q_evals + b * W * s;
+  fp P[W];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) nz |= rem.v[j];
-  if (nz) atomicOr(bad, 1u);
-}
-
-// ---- boundary quotient --------------------------------------------------------------------------------------
-// Z3 = (X^s - 1) / ((X - 1)(X - r)), r = x_last = g1^-1, has the closed form  z3_k = (1 - g1^(k+1)) / (1 - r), k < s
-// (partial fractions of 1/((X-1)(X-r)) times the two geometric sums).  out: 2s coefficients, upper half zero.
-__global__ void __launch_bounds__(TPB) stark_z3_kernel(fp* out, uint64_t steps, uint32_t ext, const fp* tw_lo, const fp* tw_hi,
-                                                       uint32_t tw_lb, fp inv_1_m_last) {
-  const uint64_t k = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (k >= 2 * steps) return;
-  fp v = fp_zero();
-  if (k < steps) {
-    const uint64_t e = ((k + 1) & (steps - 1)) * ext;  // g1^(k+1) = G2^(ext (k+1 mod s))
-    v = fp_mul(fp_sub(fp_one(), pow_lookup(tw_lo, tw_hi, tw_lb, e)), inv_1_m_last);
+  for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + i);
+  const fp x = pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i);
+  const bool last = knext == 0;
+  const fp scale = fp_mul(last ? a.x_last : fp_sub(x, a.x_last), a.inv_steps);
+#pragma unroll 1
+  for (int c = 0; c < W; ++c) {
+    const uint64_t col = (b * W + c) * N;
+    const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], P);
+    const fp cval = fp_sub(fp_load(pe + (uint64_t)c * N + inext), acc);  // witness[c][k+1] - step_c(witness[.][k])
+    fp num;
+    if (last) {
+      num = cval;  // Z(r) = s / r is not zero: D(r) = C(r) r / s
+    } else {
+      const fp cz = fp_canon(cval);
+      uint32_t nz = 0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) nz |= cz.v[w];
+      if (nz) atomicOr(a.bad, 1u);
+      // x C'(x) = Q_c(g1 x) - sum_v (d step_c / d X_v)(P(x)) Q_v(x)
+      fp dsum = fp_zero();
+#pragma unroll 1
+      for (int v = 0; v < W; ++v) {
+        const uint32_t t0 = a.dterm_begin[c * W + v], t1 = a.dterm_begin[c * W + v + 1];
+        if (t0 != t1)
+          dsum = fp_add(dsum, fp_mul(eval_terms<W>(a.dterm_coef, a.dterm_exps, t0, t1, P), fp_load(qe + (uint64_t)v * s + k)));
+      }
+      num = fp_sub(fp_load(qe + (uint64_t)c * s + knext), dsum);
+    }
+    fp_store(a.d_work + col + i, fp_mul(num, scale));
+    if (k == 0 || last) {
+      // B(1) = (P'(1) - b) / (1 - r);  B(r) = (P'(r) - b) / (r - 1),  P'(x) = Q(x) / x,  1 / r = g1
+      const fp slope = fp_load(a.iab + 2 * (b * W + c) + 1);
+      const fp qc = fp_load(qe + (uint64_t)c * s + k);
+      const fp dp = last ? fp_mul(qc, a.g1) : qc;
+      const fp v = fp_mul(fp_sub(dp, slope), a.inv_1_m_last);
+      fp_store(a.b_work + col + i, last ? fp_neg(v) : v);
+    }
   }
-  fp_store(out + k, v);
-}
-// t2[c][k] = coefficient k of P_c - I_c for k < s, zero for s <= k < 2s
-__global__ void __launch_bounds__(TPB) stark_bprep_kernel(const fp* pcoef, const fp* iab, fp* t2, uint64_t steps, uint64_t cols) {
-  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= cols * 2 * steps) return;
-  const uint64_t c = g / (2 * steps), k = g - c * 2 * steps;
-  fp v = fp_zero();
-  if (k < steps) {
-    v = fp_load(pcoef + c * steps + k);
-    if (k < 2) v = fp_sub(v, fp_load(iab + 2 * c + k));
-  }
-  fp_store(t2 + g, v);
-}
-// a[c][k] *= b[k]
-__global__ void __launch_bounds__(TPB) mul_bcast_kernel(fp* a, const fp* b, uint64_t len, uint64_t total) {
-  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= total) return;
-  fp_store(a + g, fp_mul(fp_load(a + g), fp_load(b + (g % len))));
-}
-// (P - I) Z3 = Q (X^s - 1) with deg Q < s, so Q's coefficients are the product's upper half; dst = Q zero-padded to n
-__global__ void __launch_bounds__(TPB) stark_bextract_kernel(const fp* t2, fp* dst, uint64_t steps, uint64_t n, uint64_t cols) {
-  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= cols * n) return;
-  const uint64_t c = g / n, k = g - c * n;
-  fp_store(dst + g, k < steps ? fp_load(t2 + c * 2 * steps + steps + k) : fp_zero());
 }
 
 // ---- packed Merkle leaves (merkle_tree.py:94-119) over limb-form evaluations ---------------------------------
@@ -303,11 +327,14 @@ hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, u
   return hipGetLastError();
 }
 
-hipError_t shk_stark_constraints(const StarkArgs& a, hipStream_t st) {
-  const dim3 grid(grid_for(a.n * a.batch)), block(TPB);
+hipError_t shk_stark_quotients(const StarkArgs& a, hipStream_t st) {
+  const dim3 grid(grid_for(a.n * a.batch)), tgrid(grid_for(a.steps * a.batch)), block(TPB);
   switch (a.width) {
-#define SHK_CASE(W) \
-  case W: hipLaunchKernelGGL(stark_constraint_kernel<W>, grid, block, 0, st, a); break;
+#define SHK_CASE(W)                                                           \
+  case W:                                                                     \
+    hipLaunchKernelGGL(stark_quotients_kernel<W>, grid, block, 0, st, a);     \
+    hipLaunchKernelGGL(stark_trace_points_kernel<W>, tgrid, block, 0, st, a); \
+    break;
     SHK_CASE(1) SHK_CASE(2) SHK_CASE(3) SHK_CASE(4) SHK_CASE(5) SHK_CASE(6) SHK_CASE(7) SHK_CASE(8) SHK_CASE(9)
 #undef SHK_CASE
     default: return hipErrorInvalidValue;
@@ -315,30 +342,13 @@ hipError_t shk_stark_constraints(const StarkArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t shk_stark_divide(fp* e, uint64_t steps, uint32_t ext, uint64_t cols, uint32_t* bad, hipStream_t st) {
-  hipLaunchKernelGGL(stark_divide_kernel, dim3(grid_for(cols * steps)), dim3(TPB), 0, st, e, steps, ext, cols, bad);
+hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols, hipStream_t st) {
+  hipLaunchKernelGGL(stark_qprep_kernel, dim3(grid_for(cols * steps)), dim3(TPB), 0, st, pcoef, q, steps, cols);
   return hipGetLastError();
 }
 
-hipError_t shk_stark_z3(fp* out, uint64_t steps, uint32_t ext, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb,
-                        const fp& inv_1_m_last, hipStream_t st) {
-  hipLaunchKernelGGL(stark_z3_kernel, dim3(grid_for(2 * steps)), dim3(TPB), 0, st, out, steps, ext, tw_lo, tw_hi, tw_lb,
-                     inv_1_m_last);
-  return hipGetLastError();
-}
-
-hipError_t shk_stark_bprep(const fp* pcoef, const fp* iab, fp* t2, uint64_t steps, uint64_t cols, hipStream_t st) {
-  hipLaunchKernelGGL(stark_bprep_kernel, dim3(grid_for(cols * 2 * steps)), dim3(TPB), 0, st, pcoef, iab, t2, steps, cols);
-  return hipGetLastError();
-}
-
-hipError_t shk_mul_bcast(fp* a, const fp* b, uint64_t len, uint64_t cols, hipStream_t st) {
-  hipLaunchKernelGGL(mul_bcast_kernel, dim3(grid_for(len * cols)), dim3(TPB), 0, st, a, b, len, len * cols);
-  return hipGetLastError();
-}
-
-hipError_t shk_stark_bextract(const fp* t2, fp* dst, uint64_t steps, uint64_t n, uint64_t cols, hipStream_t st) {
-  hipLaunchKernelGGL(stark_bextract_kernel, dim3(grid_for(cols * n)), dim3(TPB), 0, st, t2, dst, steps, n, cols);
+hipError_t shk_stark_inv_xm1(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, hipStream_t st) {
+  hipLaunchKernelGGL(stark_inv_xm1_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, out, n, tw_lo, tw_hi, tw_lb);
   return hipGetLastError();
 }
 
