@@ -739,3 +739,35 @@ def test_stark_batch_units_and_device_api(sa, oracle):
     dev_prove(bad)
     assert L.sh_stark_status(ctx) == -8
     assert L.sh_stark_status(ctx) == 0
+
+
+@pytest.mark.parametrize("steps,ext,width", [(2, 8, 1), (4, 8, 2), (2, 2, 1), (8, 2, 2), (16, 4, 2), (8, 16, 3), (4, 32, 1),
+                                              (128, 8, 1), (256, 4, 2)])
+def test_stark_extension_factors_and_tiny_traces(sa, oracle, steps, ext, width):
+    """Extension factors other than 8 and the smallest traces (x = 1 and x = x_last are then most of G1)."""
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import multivariates_over
+    po = oracle.py
+    rng = random.Random(steps * 1000 + ext * 10 + width)
+    maxdeg = max(1, min(3, (steps * ext - 2) // max(steps - 1, 1) - 1))
+    sp = []
+    for _ in range(width):
+        terms = {}
+        for t in range(rng.randint(1, 3)):
+            ex = [0] * width
+            for _ in range(rng.randint(0 if t else 1, maxdeg)):  # degree >= 1: with degree 0 the reference's own verifier
+                ex[rng.randrange(width)] += 1                    # rejects (FRI bound steps * 0, fri.py:351-366)
+            terms[tuple(ex)] = rng.choice([1, 2, rng.randrange(P)])
+        sp.append(terms)
+    degree = max(po.mv_degree(q) for q in sp)
+    if degree * (steps - 1) + 1 >= steps * ext:
+        pytest.skip("degree too high for this domain")
+    inputs = [rng.randrange(P) for _ in range(width)]
+    w = po.get_computational_trace(inputs, steps, sp)
+    want = po.mk_stark_proof(w, inputs, sp, steps, ext)
+    mv = multivariates_over(sa.F, width).factory
+    polys = [mv(d) for d in sp]
+    got = stark.prove_flat(b"".join(wire(col) for col in w), wire(inputs), steps, ext, width, polys)
+    assert got == po.stark_flat(want), (steps, ext, width, sp)
+    S = stark.STARK(sa.F, steps, ext, width, polys)
+    assert S.verify_proof(stark.unpack_proof(got, steps, ext, width, degree), w, [(0, j, v) for j, v in enumerate(inputs)])
