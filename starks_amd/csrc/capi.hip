@@ -94,7 +94,7 @@ struct sh_ctx {
   std::map<std::string, NttPlan*> plans;
   enum {
     WS_WIRE = 0, WS_X, WS_Y, WS_NTT, WS_TREE_A, WS_TREE_B, WS_COL_A, WS_COL_B, WS_MISC, WS_PROOF,
-    WS_ST_TRACE, WS_ST_P, WS_ST_D, WS_ST_B, WS_ST_T2, WS_ST_SMALL, WS_ST_MTREE, WS_COUNT
+    WS_ST_TRACE, WS_ST_P, WS_ST_D, WS_ST_B, WS_ST_Q, WS_ST_SMALL, WS_ST_MTREE, WS_COUNT
   };
   void* ws[WS_COUNT] = {};
   size_t ws_cap[WS_COUNT] = {};
@@ -622,7 +622,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   SH_TRY(ws_get(c, sh_ctx::WS_ST_P, cols * n * sizeof(fp), &pe));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_D, cols * n * sizeof(fp), &dw));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_B, cols * n * sizeof(fp), &bw));
-  SH_TRY(ws_get(c, sh_ctx::WS_ST_T2, cols * steps * sizeof(fp), &qv));
+  SH_TRY(ws_get(c, sh_ctx::WS_ST_Q, cols * steps * sizeof(fp), &qv));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_MTREE, (size_t)batch * 2 * n * 32, &mt));
   const size_t iab_bytes = cols * 2 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp);
   SH_TRY(ws_get(c, sh_ctx::WS_ST_SMALL, iab_bytes + scal_bytes + (size_t)batch * samples * 4, &small));

@@ -39,7 +39,6 @@ hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipS
 hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st);
 // zero-pad: dst[b][0..n_in) = src[b][0..n_in), dst[b][n_in..n) = 0
 hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st);
-// dst[b][ext*i] = src[b][i] ... not used: LDE pads coefficients, see capi
 // Merkle tree of `batch` arrays of n limb-form values (or n raw 32-byte leaves when raw_leaves).
 hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
                          hipStream_t st);
