@@ -102,9 +102,9 @@ struct sh_ctx {
   uint8_t* pin[2] = {nullptr, nullptr};
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   bool pin_busy[2] = {false, false};
-  // STARK prover state: 1/(x_i - 1) per domain size; 1/(omega^j - 1) per (steps, ext); the step-polynomial terms last
+  // STARK prover state: 1/((x_i - 1)(x_i - x_last)) and 1/(omega^j - 1) per (steps, ext); the step-polynomial terms last
   // uploaded (and their partial derivatives); the constraint flag
-  std::map<uint64_t, void*> inv_xm1;
+  std::map<std::pair<uint64_t, uint32_t>, void*> inv_z2;
   std::map<std::pair<uint64_t, uint32_t>, void*> inv_omega;
   std::vector<uint8_t> terms_key;
   void* terms_dev = nullptr;   // [terms][derivative terms]: see TermLayout
@@ -539,9 +539,10 @@ struct TermLayout {
   static constexpr size_t MAXT = SHK_STARK_MAX_TERMS, MAXD = SHK_STARK_MAX_TERMS * SHK_STARK_MAX_WIDTH;
   static constexpr size_t coef = 0;                                  // fp[MAXT]
   static constexpr size_t dcoef = coef + MAXT * sizeof(fp);          // fp[MAXD]
-  static constexpr size_t exps = dcoef + MAXD * sizeof(fp);          // u8[MAXT][W]
-  static constexpr size_t dexps = exps + MAXT * SHK_STARK_MAX_WIDTH; // u8[MAXD][W]
-  static constexpr size_t dbegin = dexps + MAXD * SHK_STARK_MAX_WIDTH;  // u32[W * W + 1]
+  static constexpr size_t ROW = SHK_STARK_MAX_WIDTH + 1;             // exponent rows: width bytes + 1 flag (coef == 1)
+  static constexpr size_t exps = dcoef + MAXD * sizeof(fp);          // u8[MAXT][width + 1]
+  static constexpr size_t dexps = exps + MAXT * ROW;                 // u8[MAXD][width + 1]
+  static constexpr size_t dbegin = (dexps + MAXD * ROW + 3) & ~(size_t)3;  // u32[W * W + 1]
   static constexpr size_t total = dbegin + 4 * (SHK_STARK_MAX_WIDTH * SHK_STARK_MAX_WIDTH + 1);
 };
 
@@ -569,8 +570,13 @@ int stark_terms(sh_ctx* c, uint32_t width, const uint8_t* coefs, const uint8_t* 
   uint8_t* ex = img.data() + TermLayout::exps;
   uint8_t* dex = img.data() + TermLayout::dexps;
   uint32_t* dbeg = reinterpret_cast<uint32_t*>(img.data() + TermLayout::dbegin);
-  for (uint64_t t = 0; t < total; ++t) cf[t] = h_from_wire(coefs + 32 * t);
-  memcpy(ex, exps, (size_t)width * total);
+  const fp one = fp_one();
+  const size_t row = width + 1;
+  for (uint64_t t = 0; t < total; ++t) {
+    cf[t] = h_from_wire(coefs + 32 * t);
+    memcpy(ex + t * row, exps + t * width, width);
+    ex[t * row + width] = fp_eq_canon(cf[t], one) ? 1 : 0;
+  }
   // d/dX_v of coef * prod X^e = (coef * e_v) * X_v^(e_v - 1) * prod_{u != v} X_u^e_u
   uint32_t begin[SHK_STARK_MAX_WIDTH + 1] = {0};
   for (uint32_t d = 0; d < width; ++d) begin[d + 1] = begin[d] + counts[d];
@@ -581,9 +587,10 @@ int stark_terms(sh_ctx* c, uint32_t width, const uint8_t* coefs, const uint8_t* 
       for (uint32_t t = begin[d]; t < begin[d + 1]; ++t) {
         const uint32_t e = exps[(size_t)t * width + v];
         if (!e) continue;
-        dcf[nd] = fp_mul(cf[t], fp_from_u32(e));
-        memcpy(dex + (size_t)nd * width, exps + (size_t)t * width, width);
-        dex[(size_t)nd * width + v] = (uint8_t)(e - 1);
+        dcf[nd] = fp_canon(fp_mul(cf[t], fp_from_u32(e)));
+        memcpy(dex + (size_t)nd * row, exps + (size_t)t * width, width);
+        dex[(size_t)nd * row + v] = (uint8_t)(e - 1);
+        dex[(size_t)nd * row + width] = fp_eq_canon(dcf[nd], one) ? 1 : 0;
         ++nd;
       }
     }
@@ -633,18 +640,20 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bad_flag), 64));
     HIP_TRY(c, hipMemsetAsync(c->bad_flag, 0, 64, c->stream));
   }
-  // cached inverses: 1 / (x_i - 1) over the domain, 1 / (omega^j - 1) for the ext-th roots of unity omega^j = x^steps
-  fp* inv_xm1 = nullptr;
+  // cached inverses: 1 / ((x_i - 1)(x_i - x_last)) over the domain, 1 / (omega^j - 1) for the ext-th roots of unity
+  // omega^j = x^steps
+  fp* inv_z2 = nullptr;
   {
-    auto it = c->inv_xm1.find(n);
-    if (it == c->inv_xm1.end()) {
+    const auto key = std::make_pair(steps, ext);
+    auto it = c->inv_z2.find(key);
+    if (it == c->inv_z2.end()) {
       void* t = nullptr;
       HIP_TRY(c, hipMalloc(&t, n * sizeof(fp)));
-      c->inv_xm1[n] = t;
-      inv_xm1 = reinterpret_cast<fp*>(t);
-      HIP_TRY(c, shk_stark_inv_xm1(inv_xm1, n, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, c->stream));
+      c->inv_z2[key] = t;
+      inv_z2 = reinterpret_cast<fp*>(t);
+      HIP_TRY(c, shk_stark_inv_z2(inv_z2, n, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, x_last, c->stream));
     } else {
-      inv_xm1 = reinterpret_cast<fp*>(it->second);
+      inv_z2 = reinterpret_cast<fp*>(it->second);
     }
   }
   fp* inv_omega = nullptr;
@@ -684,7 +693,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   a.tw_lo = fwd_n->base.lo;
   a.tw_hi = fwd_n->base.hi;
   a.tw_lb = fwd_n->base.lb;
-  a.inv_xm1 = inv_xm1;
+  a.inv_z2 = inv_z2;
   a.inv_omega = inv_omega;
   a.x_last = x_last;
   a.g1 = g1;
@@ -782,7 +791,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   }
   for (int i = 0; i < sh_ctx::WS_COUNT; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
-  for (auto& kv : c->inv_xm1) (void)hipFree(kv.second);
+  for (auto& kv : c->inv_z2) (void)hipFree(kv.second);
   for (auto& kv : c->inv_omega) (void)hipFree(kv.second);
   if (c->terms_dev) (void)hipFree(c->terms_dev);
   if (c->bad_flag) (void)hipFree(c->bad_flag);

@@ -102,14 +102,15 @@ struct StarkArgs {
   const fp* tw_lo;    // powers of G2: G2^e = lo[e & mask] (* hi[e >> lb] when hi)
   const fp* tw_hi;
   uint32_t tw_lb;
-  const fp* inv_xm1;    // [n]   1 / (x_i - 1), entry 0 = 0
+  const fp* inv_z2;     // [n]   1 / ((x_i - 1)(x_i - x_last)), 0 at the two roots
   const fp* inv_omega;  // [ext] 1 / (omega^j - 1), omega = G2^steps, entry 0 = 0
   fp x_last;          // G2^((steps - 1) ext)  (stark.py:212)
   fp g1;              // G2^ext = 1 / x_last
   fp inv_steps;       // 1 / steps
   fp inv_1_m_last;    // 1 / (1 - x_last)
   uint32_t* bad;      // set to 1 when a transition constraint fails on the trace
-  // step polynomials: term t = coef[t] * prod_v X_v^exps[t][v]; terms of dimension c: [term_begin[c], term_begin[c+1])
+  // step polynomials: term t = coef[t] * prod_v X_v^exps[t][v] (exps rows are width + 1 bytes: the last one flags
+  // coef == 1); terms of dimension c: [term_begin[c], term_begin[c+1])
   const fp* term_coef;
   const uint8_t* term_exps;
   uint32_t term_begin[SHK_STARK_MAX_WIDTH + 1];
@@ -121,7 +122,8 @@ struct StarkArgs {
 hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, uint32_t cols, const fp& inv_last_m1, fp* iab,
                             hipStream_t st);
 hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols, hipStream_t st);
-hipError_t shk_stark_inv_xm1(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, hipStream_t st);
+hipError_t shk_stark_inv_z2(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, const fp& x_last,
+                            hipStream_t st);
 hipError_t shk_stark_quotients(const StarkArgs& a, hipStream_t st);
 hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st);
 hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,

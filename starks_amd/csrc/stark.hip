@@ -8,7 +8,7 @@
 //   Z  = (X^s - 1) / (X - r)         D(x) = C(x) (x - r) / (x^s - 1)
 //   Z2 = (X - 1)(X - r)              B(x) = (P(x) - I(x)) / ((x - 1)(x - r))
 // * off the trace points (i % ext != 0): x^s - 1 = omega^(i % ext) - 1 takes ext - 1 values (omega = G2^s), whose
-//   inverses are constants; 1 / (x_i - 1) is a per-domain table T, and 1 / (x_i - r) = g1 T[i + ext].
+//   inverses are constants; 1 / ((x_i - 1)(x_i - r)) is a table cached per (steps, ext).
 // * on the trace points x in G1 the quotients are 0/0; the polynomial's value there is the formal-derivative limit
 //   (l'Hopital; exact in any field, s is invertible):  D(x) = C'(x) (x - r) x / s  for x != r,  D(r) = C(r) r / s,
 //   B(1) = (P'(1) - b) / (1 - r),  B(r) = (P'(r) - b) / (r - 1)   (I = a + b X).  With Q = X P'(X) (coefficients k p_k,
@@ -65,11 +65,18 @@ template <int W>
 __device__ __forceinline__ fp eval_terms(const fp* coef, const uint8_t* exps, uint32_t t0, uint32_t t1, const fp (&P)[W]) {
   fp acc = fp_zero();
   for (uint32_t t = t0; t < t1; ++t) {
+    const uint8_t* ex = exps + (uint64_t)t * (W + 1);
+    const bool unit = ex[W] != 0;  // coefficient 1 (the common case): the first factor starts the product
     fp prod = fp_load(coef + t);
-    const uint8_t* ex = exps + (uint64_t)t * W;
+    bool started = !unit;
 #pragma unroll
     for (int v = 0; v < W; ++v) {
-      const uint32_t e = ex[v];
+      uint32_t e = ex[v];
+      if (e && !started) {
+        prod = P[v];
+        started = true;
+        --e;
+      }
       for (uint32_t k = 0; k < e; ++k) prod = fp_mul(prod, P[v]);
     }
     acc = fp_add(acc, prod);
@@ -85,12 +92,13 @@ __global__ void __launch_bounds__(TPB) stark_qprep_kernel(const fp* pcoef, fp* q
   fp_store(q + g, fp_mul(fp_load(pcoef + g), fp_from_u32((uint32_t)k)));
 }
 
-// T[i] = 1 / (x_i - 1), T[0] = 0.  Once per domain size (cached by the context).
-__global__ void __launch_bounds__(TPB) stark_inv_xm1_kernel(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi,
-                                                            uint32_t tw_lb) {
+// U[i] = 1 / ((x_i - 1)(x_i - r)), 0 at x = 1 and x = r.  Once per (steps, ext) (cached by the context).
+__global__ void __launch_bounds__(TPB) stark_inv_z2_kernel(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi,
+                                                           uint32_t tw_lb, fp x_last) {
   const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
-  fp_store(out + i, fp_inv(fp_sub(pow_lookup(tw_lo, tw_hi, tw_lb, i), fp_one())));  // fp_inv(0) = 0
+  const fp x = pow_lookup(tw_lo, tw_hi, tw_lb, i);
+  fp_store(out + i, fp_inv(fp_mul(fp_sub(x, fp_one()), fp_sub(x, x_last))));  // fp_inv(0) = 0
 }
 
 // ---- D and B off the trace points; B on the trace points other than 1 and x_last ------------------------------
@@ -108,8 +116,7 @@ __global__ void __launch_bounds__(TPB) stark_quotients_kernel(StarkArgs a) {
 #pragma unroll
   for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + i);
   const fp x = pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i);
-  // 1 / ((x - 1)(x - r)) = T[i] * g1 * T[i + ext]      (x / r = x g1 = x_(i + ext))
-  const fp wz = fp_mul(fp_mul(fp_load(a.inv_xm1 + i), fp_load(a.inv_xm1 + inext)), a.g1);
+  const fp wz = fp_load(a.inv_z2 + i);  // 1 / ((x - 1)(x - r))
   fp f = fp_zero();
   if (j) f = fp_mul(fp_sub(x, a.x_last), fp_load(a.inv_omega + j));  // (x - r) / (x^s - 1)
 #pragma unroll 1
@@ -347,8 +354,9 @@ hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols
   return hipGetLastError();
 }
 
-hipError_t shk_stark_inv_xm1(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, hipStream_t st) {
-  hipLaunchKernelGGL(stark_inv_xm1_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, out, n, tw_lo, tw_hi, tw_lb);
+hipError_t shk_stark_inv_z2(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, const fp& x_last,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(stark_inv_z2_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, out, n, tw_lo, tw_hi, tw_lb, x_last);
   return hipGetLastError();
 }
 
