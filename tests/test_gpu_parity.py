@@ -771,3 +771,28 @@ def test_stark_extension_factors_and_tiny_traces(sa, oracle, steps, ext, width):
     assert got == po.stark_flat(want), (steps, ext, width, sp)
     S = stark.STARK(sa.F, steps, ext, width, polys)
     assert S.verify_proof(stark.unpack_proof(got, steps, ext, width, degree), w, [(0, j, v) for j, v in enumerate(inputs)])
+
+
+def test_stark_wide_state_medium_trace(sa, oracle):
+    """The reference's width-6 sextic system (test_stark.py:324-350) at 128 steps against the oracle, and a width-9
+    system at 1024 steps through both verifiers."""
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import multivariates_over
+    po = oracle.py
+    sp = [{tuple(1 if j == i else 0 for j in range(6)): 1} for i in range(5)] + [{(1, 1, 1, 1, 1, 1): 1}]
+    inputs, steps, ext = [1, 2, 3, 4, 5, 6], 128, 8
+    w = po.get_computational_trace(inputs, steps, sp)
+    mv = multivariates_over(sa.F, 6).factory
+    got = stark.prove_flat(b"".join(wire(c) for c in w), wire(inputs), steps, ext, 6, [mv(d) for d in sp])
+    assert got == po.stark_flat(po.mk_stark_proof(w, inputs, sp, steps, ext))
+    # width 9: dimension j takes x_{j+1}^2 + j (cyclically) -- every dimension moves, degree 2
+    sp9 = [{tuple(2 if v == (j + 1) % 9 else 0 for v in range(9)): 1, (0,) * 9: j + 1} for j in range(9)]
+    inputs9, steps9 = list(range(11, 20)), 1024
+    w9 = po.get_computational_trace(inputs9, steps9, sp9)
+    mv9 = multivariates_over(sa.F, 9).factory
+    polys9 = [mv9(d) for d in sp9]
+    S = stark.STARK(sa.F, steps9, ext, 9, polys9)
+    boundary = [(0, j, v) for j, v in enumerate(inputs9)]
+    pr = S.mk_proof(w9, boundary)
+    assert S.verify_proof(pr, w9, boundary)
+    assert po.verify_stark_proof(pr, [c[-1] for c in w9], inputs9, sp9, steps9, ext)
