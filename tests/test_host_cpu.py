@@ -161,3 +161,30 @@ def test_stark_host_mirror_on_reference_proofs():
         bad[2][0][0] = bytes(leaf)
         with pytest.raises(AssertionError):
             S.verify_proof(bad, witness, boundary)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/starkhip.h is C99 and a plain C program can link the library and call its host-only entry points."""
+    import subprocess
+    _build()
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "starkhip.h"
+int main(void) {
+  if (strncmp(sh_version(), "starkhip", 8)) return 1;
+  if (strcmp(sh_strerror(SH_ERR_CONSTRAINT), "the witness violates a transition constraint")) return 2;
+  if (sh_fri_proof_len(512, 512, 40) == 0) return 3;
+  if (sh_stark_proof_len(8, 8, 2, 3, 80) != 147808) return 4;   /* tests/golden/stark.json: mimc_w2_s8 */
+  if (sh_stark_proof_len(8, 8, 10, 3, 80) != 0) return 5;
+  if (sh_ntt(NULL, NULL, 0, NULL, 8, NULL, 0) != SH_ERR_INVALID) return 6;
+  printf("ok\n");
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.join(ROOT, "starks_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lstarkhip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.check_output([str(exe)]).strip() == b"ok"
