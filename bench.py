@@ -201,7 +201,7 @@ def cpu_baseline(logn, budget_s=20.0):
             break
     dt = time.time() - t0
     return {"value": 2 * n * steps / dt, "unit": "elements/s", "cores": 1, "kind": "port",
-            "sample": "%d step(s) of the same 2^%d forward+inverse NTT with oracle/oracle.c (%.1f s)" % (steps, logn, dt),
+            "sample": "%d forward+inverse NTT(s) of ONE 2^%d vector of the workload with oracle/oracle.c (%.1f s)" % (steps, logn, dt),
             "digest": hashlib.sha256(f).hexdigest()}
 
 
@@ -211,6 +211,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--logn", type=int, default=20, help="log2 transform length (configs[1] = 20)")
+    ap.add_argument("--batch", type=int, default=8, help="independent vectors transformed per step (the columns of a "
+                    "trace: one launch sequence covers all of them)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--quick", action="store_true", help="smaller secondary legs")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
@@ -240,12 +242,14 @@ def main():
     L, ctx = dev.L, dev.ctx
     n = 1 << args.logn
     w = root_of(n).to_bytes(32, "big")
-    dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
-    dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed + rank), "fill")  # an independent vector per rank
+    B = max(1, args.batch)
+    dx, dy = dev.alloc(32 * n * B), dev.alloc(32 * n * B)
+    dev.ck(L.sh_dev_fill_seeded(ctx, dx, n * B, 0x5eed + rank), "fill")  # independent vectors per rank; vector 0 of
+    # rank 0 is the input of the reference-generated fixture
 
     def step():
-        dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt")   # y = NTT(x)
-        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")  # y = invNTT(y) == x
+        dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, B, w, 0), "ntt")   # y = NTT(x), every vector
+        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, B, w, 1), "intt")  # y = invNTT(y) == x
 
     def fence():
         dev.sync()
@@ -271,13 +275,13 @@ def main():
     dt_max = float(tmax.item())
 
     # correctness of what was timed: x == invNTT(NTT(x)) and the forward digest against the fixture (rank 0)
-    a, b = ctypes.create_string_buffer(32 * n), ctypes.create_string_buffer(32 * n)
-    dev.ck(L.sh_dev_to_wire(ctx, dx, a, n), "dl")
-    dev.ck(L.sh_dev_to_wire(ctx, dy, b, n), "dl")
+    a, b = ctypes.create_string_buffer(32 * n * B), ctypes.create_string_buffer(32 * n * B)
+    dev.ck(L.sh_dev_to_wire(ctx, dx, a, n * B), "dl")
+    dev.ck(L.sh_dev_to_wire(ctx, dy, b, n * B), "dl")
     roundtrip_ok = a.raw == b.raw
-    dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt")
+    dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, B, w, 0), "ntt")
     dev.ck(L.sh_dev_to_wire(ctx, dy, b, n), "dl")
-    fwd_digest = hashlib.sha256(b.raw).hexdigest()
+    fwd_digest = hashlib.sha256(b.raw[:32 * n]).hexdigest()  # vector 0
     golden_ok = None
     try:
         gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ntt.json")))
@@ -290,14 +294,14 @@ def main():
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the only exchange: a 1-word status gather over RCCL
 
-    elems_per_step = 2 * n
+    elems_per_step = 2 * n * B
     value = elems_per_step * args.steps * world / dt_max
     alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
     achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
     traffic, traffic_src = None, None
     try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_traffic.sh)
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if args.logn == 20:
+        if args.logn == 20 and tj.get("vectors_per_step", 1) == B:
             traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
             traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
     except Exception:
@@ -308,15 +312,17 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU)",
         "data": "synthetic", "config": {
-            "workload": "configs[1]: 2^%d-point NTT + inverse NTT over the MiMC prime, one vector per GPU, "
-                        "x == invNTT(NTT(x)) checked" % args.logn,
-            "n": n, "elements_per_step": elems_per_step, "parallelism": "independent vectors x%d" % world},
-        "field_mul_eq_per_s": (n // 2) * args.logn * 2 * args.steps * world / dt_max,
+            "workload": "configs[1]: 2^%d-point NTT + inverse NTT over the MiMC prime, %d independent vectors per step "
+                        "per GPU (the columns of a trace, one launch sequence), x == invNTT(NTT(x)) checked on all; "
+                        "the single-vector figure is extra.ntt_2^%d_single_vector" % (args.logn, B, args.logn),
+            "n": n, "vectors_per_step": B, "elements_per_step": elems_per_step,
+            "parallelism": "independent vectors x%d" % world},
+        "field_mul_eq_per_s": (n // 2) * args.logn * 2 * B * args.steps * world / dt_max,
         "check": {"roundtrip_ok": bool(int(ok.item())), "fwd_sha256": fwd_digest, "matches_reference_fixture": golden_ok},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                      "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": 64.0 * n / passes,
+                     "algorithmic_bytes_per_launch": 64.0 * n * B / passes,
                      "kernel": "ntt_pass_kernel (%d launches per 2^%d transform)" % (passes, args.logn),
                      "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
                      "note": "integer-VALU bound, not HBM bound: ~11 256-bit modmuls + 20 add/sub per element per "
@@ -328,6 +334,11 @@ def main():
             line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
         if not args.no_extras:
             line["extra"] = extras(dev, args.quick)
+            # the same transform pair on ONE vector (a launch's load / store phases are then exposed: nothing else runs)
+            single = dev.timed(lambda: (dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"),
+                                        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")), 50)
+            line["extra"]["ntt_2^%d_single_vector" % args.logn] = {
+                "ms_per_fwd_inv": round(single, 5), "elements_per_s": 2 * n / single * 1e3}
     dev.free(dx)
     dev.free(dy)
     if rank == 0:

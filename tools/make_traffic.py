@@ -15,8 +15,10 @@ def durations(root):
     return {r["Name"]: (int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(f))}
 if __name__ == "__main__":
     fdir, wdir, sdir, out = sys.argv[1:5]
+    vectors = int(sys.argv[5]) if len(sys.argv) > 5 else 8  # bench.py --batch of the profiled command
     F, W, D = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE"), durations(sdir)
-    res = {"workload": "bench.py default: 2^20-point NTT + inverse NTT", "unit": "bytes per launch",
+    res = {"workload": "bench.py default: 2^20-point NTT + inverse NTT, %d vectors per step" % vectors,
+           "vectors_per_step": vectors, "unit": "bytes per launch",
            "correction": "2*FETCH_SIZE + WRITE_SIZE, counters in KiB (gfx950: FETCH_SIZE = 1/2 of a wide coalesced stream)",
            "kernels": {}}
     tot_b = tot_n = 0
