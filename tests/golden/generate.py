@@ -466,6 +466,9 @@ STARK_CASES = [
     ("cubic_w1_s16", 1, 16, [3], [{(3,): 1, (0,): 7}]),
     ("mimc_w2_s64", 2, 64, [2, 5], [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]),
     ("mixed_w3_s16", 3, 16, [1, 2, 3], [{(0, 1, 0): 1}, {(1, 0, 1): 2, (0, 0, 0): 5}, {(0, 2, 0): 1, (1, 0, 0): 1}]),
+    # larger traces: three FRI rounds; minutes of O(n^2) polynomial arithmetic in the reference
+    ("mimc_w2_s256", 2, 256, [7, 11], [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]),
+    ("fib_w2_s512", 2, 512, [1, 1], [{(0, 1): 1}, {(1, 0): 1, (0, 1): 1}]),
 ]
 
 
