@@ -675,7 +675,7 @@ def test_stark_shape_errors(sa):
         stark.prove_flat(wire([1] * 8), wire([1]), 8, 8, 1, [X**9])
 
 
-@pytest.mark.parametrize("logsteps", [10, 14])
+@pytest.mark.parametrize("logsteps", [10, 14, 16, 20])
 def test_stark_large_prove_then_verify(sa, oracle, logsteps):
     """Sizes the coefficient-form oracle cannot reach: prove on the device, verify with the host verifier and with the
     oracle's restated verifier (transition + boundary identities at 80 positions, FRI on the linear combination)."""
@@ -695,8 +695,11 @@ def test_stark_large_prove_then_verify(sa, oracle, logsteps):
     # the P evaluations inside the leaves are the low-degree extension of the witness
     pos = sa.utils.get_pseudorandom_indices(pr[1], steps * ext, 80, exclude_multiples_of=ext)[0]
     leaf = sa.mt.unpack_merkle_leaf(pr[2][0][0], 2, 3)
-    lde = oracle.c.lde_bytes(wire(w[1]), ext, root_of(steps * ext))
-    assert leaf[1] == lde[32 * pos:32 * pos + 32]
+    if logsteps <= 16:
+        lde = oracle.c.lde_bytes(wire(w[1]), ext, root_of(steps * ext))
+        assert leaf[1] == lde[32 * pos:32 * pos + 32]
+    # the committed trace values are the witness itself: P(g1^k) = witness[.][k] at an untouched trace point is implied by
+    # the boundary + transition identities the verifiers checked at 80 random points of a degree < steps polynomial
 
 
 def test_stark_batch_units_and_device_api(sa, oracle):
