@@ -770,10 +770,16 @@ int sh_ctx_create(int device, sh_ctx** out) {
   if (!out) return SH_ERR_INVALID;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return SH_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SH_ERR_NO_DEVICE;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return SH_ERR_NO_DEVICE;  // the code objects are gfx950 only
   sh_ctx* c = new sh_ctx();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SH_ERR_HIP;
   }
@@ -809,16 +815,19 @@ const char* sh_last_error(const sh_ctx* c) { return c ? c->err.c_str() : ""; }
 
 int sh_sync(sh_ctx* c) {
   if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SH_OK;
 }
 int sh_timer_start(sh_ctx* c) {
   if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   return SH_OK;
 }
 int sh_timer_stop(sh_ctx* c, float* ms) {
   if (!c || !ms) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   HIP_TRY(c, hipEventSynchronize(c->ev1));
   HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -834,22 +843,26 @@ int sh_dev_alloc(sh_ctx* c, uint64_t bytes, void** dptr) {
 }
 int sh_dev_free(sh_ctx* c, void* dptr) {
   if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipFree(dptr));
   return SH_OK;
 }
 int sh_dev_upload(sh_ctx* c, const void* host_src, void* d_dst, uint64_t bytes) {
   if (!c || (!host_src && bytes) || (!d_dst && bytes)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   SH_TRY(h2d(c, d_dst, host_src, bytes));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return SH_OK;
 }
 int sh_dev_download(sh_ctx* c, const void* d_src, void* host_dst, uint64_t bytes) {
   if (!c || (!host_dst && bytes) || (!d_src && bytes)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   return d2h(c, host_dst, d_src, bytes);
 }
 int sh_dev_from_wire(sh_ctx* c, const uint8_t* host_wire, void* d_limbs, uint64_t n) {
   if (!c || (n && (!host_wire || !d_limbs))) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   void* w = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, n * 32, &w));
   SH_TRY(h2d(c, w, host_wire, n * 32));
@@ -859,6 +872,7 @@ int sh_dev_from_wire(sh_ctx* c, const uint8_t* host_wire, void* d_limbs, uint64_
 }
 int sh_dev_to_wire(sh_ctx* c, const void* d_limbs, uint8_t* host_wire, uint64_t n) {
   if (!c || (n && (!host_wire || !d_limbs))) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   void* w = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, n * 32, &w));
   HIP_TRY(c, shk_limb_to_wire(reinterpret_cast<const fp*>(d_limbs), reinterpret_cast<uint8_t*>(w), n, c->stream));
@@ -866,18 +880,21 @@ int sh_dev_to_wire(sh_ctx* c, const void* d_limbs, uint8_t* host_wire, uint64_t 
 }
 int sh_dev_fill_seeded(sh_ctx* c, void* d_limbs, uint64_t n, uint64_t seed) {
   if (!c || (n && !d_limbs)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, shk_fill_seeded(reinterpret_cast<fp*>(d_limbs), n, seed, c->stream));
   return SH_OK;
 }
 int sh_dev_ntt(sh_ctx* c, const void* d_in, void* d_out, uint64_t n, uint32_t batch, const uint8_t root[32],
                int inverse) {
   if (!c || !d_in || !d_out || !root) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
   return run_ntt(c, pl, reinterpret_cast<const fp*>(d_in), reinterpret_cast<fp*>(d_out), batch);
 }
 int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t ext, uint32_t cols, const uint8_t g2[32]) {
   if (!c || !d_trace || !d_out || !g2 || cols == 0 || !is_pow2(steps) || !is_pow2(ext)) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t n = steps * ext;
   NttPlan *inv1 = nullptr, *fwd2 = nullptr;
   SH_TRY(plan_for(c, g2, n, false, &fwd2));
@@ -892,12 +909,14 @@ int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t e
 }
 int sh_dev_merkelize(sh_ctx* c, const void* d_values, uint64_t n, uint32_t batch, void* d_nodes) {
   if (!c || !d_values || !d_nodes || !is_pow2(n) || n < 4 || batch == 0) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, shk_merkelize(d_values, false, n, batch, reinterpret_cast<uint32_t*>(d_nodes), c->stream));
   return SH_OK;
 }
 int sh_dev_fri_fold(sh_ctx* c, const void* d_values, const void* d_nodes, uint64_t n, uint32_t batch,
                     const uint8_t root[32], void* d_column) {
   if (!c || !d_values || !d_nodes || !d_column || !root || n < 4) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, false, &pl));
   FoldArgs fa;
@@ -920,6 +939,7 @@ int sh_dev_fri_fold(sh_ctx* c, const void* d_values, const void* d_nodes, uint64
 int sh_dev_fri_prove(sh_ctx* c, const void* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
                      uint32_t exclude, uint32_t samples, uint32_t batch, void* d_proof) {
   if (!c || !root) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
   return run_fri(c, reinterpret_cast<const fp*>(d_coeffs), n, root, maxdeg_plus_1, exclude, samples, batch,
                  reinterpret_cast<uint8_t*>(d_proof));
 }
