@@ -63,6 +63,12 @@ PROBE(k_add3, "v_add3_u32 %0, %0, %8, %1\n v_add3_u32 %1, %1, %8, %2\n v_add3_u3
               "v_add3_u32 %4, %4, %8, %5\n v_add3_u32 %5, %5, %8, %6\n v_add3_u32 %6, %6, %8, %7\n v_add3_u32 %7, %7, %8, %0\n")
 PROBE(k_xor, "v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8\n")
 PROBE(k_alignbit, "v_alignbit_b32 %0, %0, %0, 7\n v_alignbit_b32 %1, %1, %1, 7\n v_alignbit_b32 %2, %2, %2, 7\n v_alignbit_b32 %3, %3, %3, 7\n v_alignbit_b32 %4, %4, %4, 7\n v_alignbit_b32 %5, %5, %5, 7\n v_alignbit_b32 %6, %6, %6, 7\n v_alignbit_b32 %7, %7, %7, 7\n")
+PROBE(k_perm, "v_perm_b32 %0, %0, %0, %8\n v_perm_b32 %1, %1, %1, %8\n v_perm_b32 %2, %2, %2, %8\n v_perm_b32 %3, %3, %3, %8\n v_perm_b32 %4, %4, %4, %8\n v_perm_b32 %5, %5, %5, %8\n v_perm_b32 %6, %6, %6, %8\n v_perm_b32 %7, %7, %7, %8\n")
+PROBE(k_xor_sdwa, "v_xor_b32_sdwa %0, %0, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n v_xor_b32_sdwa %1, %1, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n v_xor_b32_sdwa %2, %2, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n v_xor_b32_sdwa %3, %3, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n"
+                  "v_xor_b32_sdwa %4, %4, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n v_xor_b32_sdwa %5, %5, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n v_xor_b32_sdwa %6, %6, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n v_xor_b32_sdwa %7, %7, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0\n")
+PROBE(k_xad, "v_xad_u32 %0, %0, %8, %1\n v_xad_u32 %1, %1, %8, %2\n v_xad_u32 %2, %2, %8, %3\n v_xad_u32 %3, %3, %8, %4\n v_xad_u32 %4, %4, %8, %5\n v_xad_u32 %5, %5, %8, %6\n v_xad_u32 %6, %6, %8, %7\n v_xad_u32 %7, %7, %8, %0\n")
+PROBE(k_and_or, "v_and_or_b32 %0, %0, %8, %1\n v_and_or_b32 %1, %1, %8, %2\n v_and_or_b32 %2, %2, %8, %3\n v_and_or_b32 %3, %3, %8, %4\n v_and_or_b32 %4, %4, %8, %5\n v_and_or_b32 %5, %5, %8, %6\n v_and_or_b32 %6, %6, %8, %7\n v_and_or_b32 %7, %7, %8, %0\n")
+PROBE(k_lshlrev, "v_lshlrev_b32 %0, 7, %0\n v_lshlrev_b32 %1, 7, %1\n v_lshlrev_b32 %2, 7, %2\n v_lshlrev_b32 %3, 7, %3\n v_lshlrev_b32 %4, 7, %4\n v_lshlrev_b32 %5, 7, %5\n v_lshlrev_b32 %6, 7, %6\n v_lshlrev_b32 %7, 7, %7\n")
 // one dependent chain of v_mad_u64_u32 per lane: latency
 __global__ void __launch_bounds__(256) k_mad64_dep(uint32_t* out, uint32_t seed) {
   uint64_t a0 = threadIdx.x + seed;
@@ -355,7 +361,9 @@ int main() {
                 {"v_dot4_u32_u8", k_dot4, 8},        {"v_mad_u64_u32", k_mad64, 8}, {"v_fma_f64", k_fma64, 8},
                 {"v_add_co_u32 (indep)", k_addco, 8}, {"v_addc_co_u32 (indep)", k_addc_indep, 8}, {"v_mov_b32", k_mov, 8},
                 {"v_cndmask_b32", k_cndmask, 8}, {"v_add3_u32", k_add3, 8}, {"v_xor_b32", k_xor, 8}, {"v_alignbit_b32", k_alignbit, 8},
-                {"v_mad_u64_u32 dep chain", k_mad64_dep, 8}, {"v_lshl_add_u64", k_lshladd64, 8}};
+                {"v_mad_u64_u32 dep chain", k_mad64_dep, 8}, {"v_lshl_add_u64", k_lshladd64, 8},
+                {"v_perm_b32", k_perm, 8}, {"v_xor_b32 sdwa", k_xor_sdwa, 8}, {"v_xad_u32", k_xad, 8},
+                {"v_and_or_b32", k_and_or, 8}, {"v_lshlrev_b32", k_lshlrev, 8}};
   for (auto& p : probes) {
     double s = time_kernel([&] { hipLaunchKernelGGL(p.k, dim3(blocks), dim3(threads), 0, 0, dout, 1u); });
     double lane_ops = (double)nthreads * ITERS * p.per_iter;
