@@ -21,7 +21,7 @@ def get_power_cycle(r, field):
 
 def get_pseudorandom_indices(entropy, modulus, count, exclude_multiples_of=0):
     """utils.py:60-90 (Fiat-Shamir query positions).  Host restatement for verifiers / callers; the
-    prover's device kernel (csrc/kernels.hip:fri_sample_kernel) produces the same numbers."""
+    prover's device kernel (csrc/kernels.hip:sample_indices_kernel) produces the same numbers."""
     assert modulus < 2**24
     data = entropy
     while len(data) < 4 * count:
