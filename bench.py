@@ -184,25 +184,28 @@ def extras(dev, quick):
     return out
 
 
-def cpu_baseline(logn, budget_s=20.0):
-    """The C oracle (reference algorithm, scalar, 1 core) on the same forward+inverse workload."""
-    from oracle import coracle
-    import struct
+def cpu_baseline(logn, vectors, budget_s=10.0):
+    """The C oracle (the reference's algorithm, scalar code) on the same workload: the step's independent vectors are
+    spread over host cores, one child process per vector (oracle/cpu_worker.py), at most the cores this box gives us."""
+    import subprocess
     n = 1 << logn
-    data = b"".join(hashlib.blake2s(struct.pack("<QQ", 0x5eed, i)).digest() for i in range(n))
-    w = root_of(n)
+    cores = max(1, min(vectors, os.cpu_count() or 1, 16))
     t0 = time.time()
-    steps = 0
-    while True:
-        f = coracle.fft_bytes(data, n, w)
-        coracle.fft_bytes(f, n, w, inverse=True)
-        steps += 1
-        if time.time() - t0 > budget_s / 2 or steps >= 8:
-            break
-    dt = time.time() - t0
-    return {"value": 2 * n * steps / dt, "unit": "elements/s", "cores": 1, "kind": "port",
-            "sample": "%d forward+inverse NTT(s) of ONE 2^%d vector of the workload with oracle/oracle.c (%.1f s)" % (steps, logn, dt),
-            "digest": hashlib.sha256(f).hexdigest()}
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(logn), str(b), str(budget_s)], cwd=ROOT,
+                              stdout=subprocess.PIPE) for b in range(cores)]
+    res = []
+    for pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("cpu_baseline worker failed")
+        res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    wall = time.time() - t0
+    rate = sum(2 * n * r["reps"] / r["seconds"] for r in res)  # the workers run concurrently for their whole window
+    return {"value": rate, "unit": "elements/s", "cores": cores, "kind": "port",
+            "sample": "%d of the step's %d vectors, one per core; %s forward+inverse 2^%d NTTs each with oracle/oracle.c "
+                      "(%.1f s per worker, %.1f s wall)" % (cores, vectors, "/".join(str(r["reps"]) for r in res), logn,
+                                                            max(r["seconds"] for r in res), wall),
+            "roundtrip_ok": all(r["roundtrip_ok"] for r in res), "digest": res[0]["fwd_sha256"]}
 
 
 def main():
@@ -330,7 +333,7 @@ def main():
     }
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.logn)
+            line["cpu_baseline"] = cpu_baseline(args.logn, B)
             line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
         if not args.no_extras:
             line["extra"] = extras(dev, args.quick)
