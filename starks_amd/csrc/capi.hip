@@ -460,7 +460,7 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   const fp inv_4 = h_inv(fp_from_u32(4u));
   while (md > 16) {
     const uint32_t s = round == 0 ? samples : 40;
-    if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream));  // m = merkelize(values), fri.py:224
+    if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream, false));  // m = merkelize(values), fri.py:224
     FoldArgs fa;
     memset(&fa, 0, sizeof fa);
     fa.values = vals;
@@ -476,9 +476,11 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
     fa.inv_i = inv_i;
     fa.inv_4 = inv_4;
     HIP_TRY(c, shk_fri_fold(fa, c->stream));                                   // column, fri.py:235-242
-    HIP_TRY(c, shk_merkelize(next, false, nn / 4, batch, tree2, c->stream));   // m2, fri.py:243
+    HIP_TRY(c, shk_merkelize(next, false, nn / 4, batch, tree2, c->stream, false));   // m2, fri.py:243
     SampleArgs sa;
     memset(&sa, 0, sizeof sa);
+    sa.values = vals;
+    sa.column = next;
     sa.nodes_m = tree;
     sa.nodes_m2 = tree2;
     sa.n = nn;
@@ -728,11 +730,11 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   SH_TRY(fri_buffers(c, n, batch, samples, &fb));
   HIP_TRY(c, shk_stark_scalars(mtree, 2 * n * 8, width, batch, cpow, scal, c->stream));
   HIP_TRY(c, shk_stark_lincomb(a, scal, fb.vals, c->stream));
-  HIP_TRY(c, shk_merkelize(fb.vals, false, n, batch, fb.tree, c->stream));   // l_mtree
+  HIP_TRY(c, shk_merkelize(fb.vals, false, n, batch, fb.tree, c->stream, false));   // l_mtree
   // spot checks (stark.py:390-402)
   const uint64_t stride = stark_header_len(n, width, samples) + fri_proof_len(n, steps * (uint64_t)degree, 40);
   HIP_TRY(c, shk_sample_indices(fb.tree, 2 * n * 8, (uint32_t)n, batch, samples, ext, ys, c->stream));
-  HIP_TRY(c, shk_stark_gather(a, mtree, fb.tree, ys, samples, d_proof, stride, c->stream));
+  HIP_TRY(c, shk_stark_gather(a, mtree, fb.tree, fb.vals, ys, samples, d_proof, stride, c->stream));
   // fri.generate_proximity_proof(l_poly, G2, steps * degree, exclude_multiples_of=ext) (stark.py:271-276); its first
   // tree is l_mtree
   return fri_rounds(c, fwd_n, fb, n, steps * (uint64_t)degree, ext, 40, batch, d_proof + stark_header_len(n, width, samples),

@@ -40,8 +40,9 @@ hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t
 // zero-pad: dst[b][0..n_in) = src[b][0..n_in), dst[b][n_in..n) = 0
 hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st);
 // Merkle tree of `batch` arrays of n limb-form values (or n raw 32-byte leaves when raw_leaves).
+// store_leaves = false leaves nodes[n, 2n) unwritten (limb-form input only): for callers that gather leaves from the values
 hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
-                         hipStream_t st);
+                         hipStream_t st, bool store_leaves = true);
 hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st);
 // packed leaves (merkle_tree.py:94-119): d_evals [k][n][32 B] wire; d_leaves [n][k][32 B] permuted; d_nodes [n][32 B]
 hipError_t shk_merkelize_packed(const uint8_t* d_evals, uint64_t n, uint32_t k, uint8_t* d_leaves, uint32_t* d_nodes,
@@ -65,6 +66,8 @@ struct FoldArgs {
 hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st);
 // ys[b][s] from the column tree's root (utils.py:60-90), then copy 5 branches per sample into the proof
 struct SampleArgs {
+  const fp* values;          // [batch][n]   the values under nodes_m  (leaves are re-derived from them)
+  const fp* column;          // [batch][n/4] the values under nodes_m2
   const uint32_t* nodes_m;   // [batch][2n][8]   tree of the values
   const uint32_t* nodes_m2;  // [batch][2q][8]   tree of the column (q = n/4)
   uint64_t n;
@@ -129,5 +132,5 @@ hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_
 hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
                              fp* d_scal, hipStream_t st);
 hipError_t shk_stark_lincomb(const StarkArgs& a, const fp* d_scal, fp* d_l, hipStream_t st);
-hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const uint32_t* d_ys,
-                            uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st);
+hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const fp* d_lvals,
+                            const uint32_t* d_ys, uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st);

@@ -109,7 +109,9 @@ __device__ __forceinline__ void unpack4(const uint4& v, uint32_t* w) { w[0] = v.
 
 // One thread per row i of permute4 (merkle_tree.py:11-23): the 4 leaves 4i..4i+3 (wire form) and the three
 // nodes above them.  grid = (ceil(n/4 / 256), batch).
-template <bool RAW>
+// STORE = false skips writing the leaf level (a third of the kernel's traffic): the callers that keep the value array
+// alive next to the tree (FRI rounds, the STARK l tree) re-derive a sampled leaf from its value when they gather branches.
+template <bool RAW, bool STORE>
 __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, uint64_t n, uint32_t* nodes) {
   __shared__ uint4 lds[TPB * 8];
   const uint64_t q = n >> 2;
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, 
       fp_to_wire_words(v, w[j]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
     }
   }
-  {
+  if (STORE) {
     uint4 v[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -359,18 +361,25 @@ __global__ void __launch_bounds__(TPB) fri_gather_kernel(SampleArgs a, uint32_t 
   const uint32_t s = (uint32_t)(r / per_sample), slot = (uint32_t)(r - (uint64_t)s * per_sample);
   const uint32_t y = a.ys[b * a.samples + s];
   const uint32_t* tree;
+  const fp* vals;
   uint64_t leaves, index;
   uint32_t lev;
   if (slot < l2) {
-    tree = m2; leaves = q; index = y; lev = slot;
+    tree = m2; vals = a.column + b * q; leaves = q; index = y; lev = slot;
   } else {
     const uint32_t br = (slot - l2) / l1;
-    tree = m; leaves = a.n; index = y + q * br; lev = (slot - l2) - br * l1;
+    tree = m; vals = a.values + b * a.n; leaves = a.n; index = y + q * br; lev = (slot - l2) - br * l1;
   }
   const uint64_t ld4 = leaves >> 2;  // get_index_in_permuted (merkle_tree.py:26-33)
-  uint64_t idx = index / ld4 + 4 * (index % ld4) + leaves;
-  const uint64_t node = lev == 0 ? idx : ((idx >> (lev - 1)) ^ 1);
-  load8(tree + node * 8, w);
+  const uint64_t pi = index / ld4 + 4 * (index % ld4);
+  if (lev <= 1) {
+    // branch entries 0 and 1 are the leaf and its sibling leaf = x.to_bytes() of the values (merkle_tree.py:47-53), which
+    // the internal trees do not materialise: permuted slot pi (or pi ^ 1) holds the value at (pi & 3) * n/4 + (pi >> 2)
+    const uint64_t ps = pi ^ lev;
+    fp_to_wire_words(fp_canon(fp_load(vals + (ps & 3) * ld4 + (ps >> 2))), w);
+  } else {
+    load8(tree + (((pi + leaves) >> (lev - 1)) ^ 1) * 8, w);
+  }
   store8(out + 8 + ((uint64_t)s * per_sample + slot) * 8, w);
 }
 __global__ void __launch_bounds__(TPB) fri_final_kernel(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof,
@@ -418,13 +427,15 @@ hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint3
   return hipGetLastError();
 }
 hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
-                         hipStream_t st) {
+                         hipStream_t st, bool store_leaves) {
   if (n < 4 || (n & (n - 1)) || batch == 0) return hipErrorInvalidValue;
   const dim3 lgrid(grid_for(n >> 2), batch);
   if (raw_leaves)
-    hipLaunchKernelGGL(merkle_leaves_kernel<true>, lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
+    hipLaunchKernelGGL((merkle_leaves_kernel<true, true>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
+  else if (store_leaves)
+    hipLaunchKernelGGL((merkle_leaves_kernel<false, true>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
   else
-    hipLaunchKernelGGL(merkle_leaves_kernel<false>, lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
+    hipLaunchKernelGGL((merkle_leaves_kernel<false, false>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return shk_merkle_upper_levels(n, batch, d_nodes, st);

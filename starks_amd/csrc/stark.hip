@@ -281,8 +281,8 @@ __global__ void __launch_bounds__(TPB) stark_lincomb_kernel(StarkArgs a, const f
 // A packed branch = leaf (k values) | sibling leaf (k values) | log2(n) - 1 nodes; an l branch = log2(n) + 1 nodes.
 // One thread per 32-byte slot.
 __global__ void __launch_bounds__(TPB) stark_gather_kernel(StarkArgs a, const uint32_t* mnodes, const uint32_t* lnodes,
-                                                           const uint32_t* ys, uint32_t samples, uint32_t lg, uint8_t* proof,
-                                                           uint64_t stride) {
+                                                           const fp* lvals, const uint32_t* ys, uint32_t samples, uint32_t lg,
+                                                           uint8_t* proof, uint64_t stride) {
   const uint32_t k = 3 * a.width;
   const uint32_t pb = 2 * k + (lg - 1), lb = lg + 1, per_sample = 2 * pb + lb;
   const uint64_t per_proof = 2 + (uint64_t)samples * per_sample;
@@ -319,9 +319,13 @@ __global__ void __launch_bounds__(TPB) stark_gather_kernel(StarkArgs a, const ui
     }
   } else {
     slot -= 2 * pb;
-    const uint64_t idx = n + pos / q + 4 * (pos % q);
-    const uint64_t node = slot == 0 ? idx : ((idx >> (slot - 1)) ^ 1);
-    load8(lt + node * 8, w);
+    const uint64_t pi = pos / q + 4 * (pos % q);
+    if (slot <= 1) {  // the leaf and its sibling leaf: the l tree's leaf level is not materialised either
+      const uint64_t ps = pi ^ slot;
+      fp_to_wire_words(fp_canon(fp_load(lvals + b * n + (ps & 3) * q + (ps >> 2))), w);
+    } else {
+      load8(lt + (((n + pi) >> (slot - 1)) ^ 1) * 8, w);
+    }
   }
   store8(out, w);
 }
@@ -378,13 +382,13 @@ hipError_t shk_stark_lincomb(const StarkArgs& a, const fp* d_scal, fp* d_l, hipS
   return hipGetLastError();
 }
 
-hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const uint32_t* d_ys,
-                            uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st) {
+hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const fp* d_lvals,
+                            const uint32_t* d_ys, uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st) {
   uint32_t lg = 0;
   while ((1ull << lg) < a.n) ++lg;
   const uint32_t k = 3 * a.width;
   const uint64_t per_proof = 2 + (uint64_t)samples * (2 * (2 * k + (lg - 1)) + (lg + 1));
-  hipLaunchKernelGGL(stark_gather_kernel, dim3(grid_for(per_proof * a.batch)), dim3(TPB), 0, st, a, d_mnodes, d_lnodes, d_ys,
-                     samples, lg, d_proof, stride);
+  hipLaunchKernelGGL(stark_gather_kernel, dim3(grid_for(per_proof * a.batch)), dim3(TPB), 0, st, a, d_mnodes, d_lnodes, d_lvals,
+                     d_ys, samples, lg, d_proof, stride);
   return hipGetLastError();
 }
