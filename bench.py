@@ -188,6 +188,8 @@ def cpu_baseline(logn, vectors, budget_s=10.0):
     """The C oracle (the reference's algorithm, scalar code) on the same workload: the step's independent vectors are
     spread over host cores, one child process per vector (oracle/cpu_worker.py), at most the cores this box gives us."""
     import subprocess
+    from oracle import coracle
+    coracle.build()  # once, before the workers race for it
     n = 1 << logn
     cores = max(1, min(vectors, os.cpu_count() or 1, 16))
     t0 = time.time()
