@@ -799,3 +799,36 @@ def test_stark_wide_state_medium_trace(sa, oracle):
     pr = S.mk_proof(w9, boundary)
     assert S.verify_proof(pr, w9, boundary)
     assert po.verify_stark_proof(pr, [c[-1] for c in w9], inputs9, sp9, steps9, ext)
+
+
+def test_full_size_merkle_2_24_branches_verify(sa):
+    """A 2^24-leaf tree (1 GiB of nodes) built on the device: random branches, fetched node by node, verify against the
+    root with the host verifier, and their leaves are the seeded values (merkle_tree.py:59-86)."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << 24
+    dx, dt = ctypes.c_void_p(), ctypes.c_void_p()
+    sa.lib.check(L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dx)), "alloc")
+    sa.lib.check(L.sh_dev_alloc(ctx, 64 * n, ctypes.byref(dt)), "alloc")
+    try:
+        sa.lib.check(L.sh_dev_fill_seeded(ctx, dx, n, 99), "fill")
+        sa.lib.check(L.sh_dev_merkelize(ctx, dx, n, 1, dt), "merkelize")
+
+        def node(i):
+            buf = ctypes.create_string_buffer(32)
+            sa.lib.check(L.sh_dev_download(ctx, ctypes.c_void_p(dt.value + 32 * i), buf, 32), "download")
+            return buf.raw
+        root = node(1)
+        assert node(0) == bytes(32)
+        rng = random.Random(24)
+        for index in [0, 1, n // 4, n // 4 + 1, n - 1] + [rng.randrange(n) for _ in range(6)]:
+            idx = sa.mt.get_index_in_permuted(index, n) + n
+            branch = [node(idx)]
+            while idx > 1:
+                branch.append(node(idx ^ 1))
+                idx //= 2
+            assert len(branch) == 25
+            assert sa.mt.verify_branch(root, index, branch, output_as_int=True) == seeded(99, index)
+    finally:
+        L.sh_dev_free(ctx, dx)
+        L.sh_dev_free(ctx, dt)
