@@ -504,8 +504,12 @@ def test_two_process_sharded_proving(sa, oracle, tmp_path):
         proofs = batch.prove_mimc_batch(mine, 128, chunk=2)
         digs = batch.gather_digests([batch.digest(p) for _, p in proofs], 6, rank, world, dist, "cpu")
         open(os.path.join(%r, "rank%%d.txt" %% rank), "w").write(",".join(d.hex() for d in digs))
+        # the same units as full STARK proofs (config 5's unit of work)
+        sproofs = batch.prove_stark_batch(mine, 64, chunk=2)
+        sdigs = batch.gather_digests([batch.digest(p) for _, p in sproofs], 6, rank, world, dist, "cpu")
+        open(os.path.join(%r, "stark_rank%%d.txt" %% rank), "w").write(",".join(d.hex() for d in sdigs))
         dist.destroy_process_group()
-    """ % (ROOT, str(tmp_path))))
+    """ % (ROOT, str(tmp_path), str(tmp_path))))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", "29547", str(script)],
@@ -517,8 +521,15 @@ def test_two_process_sharded_proving(sa, oracle, tmp_path):
     for j in range(6):
         c = oracle.c.fft(oracle.py.mimc_trace(3 + j, steps), steps, pow(g2, 8, P), inverse=True)
         want.append(hashlib.sha256(oracle.c.fri_prove_flat(wire(c), g2, steps, 8, 40)).hexdigest())
+    from starks_amd import batch
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    swant = []
+    for j in range(6):
+        w, inp = batch.mimc_stark_unit(j, 64)
+        swant.append(hashlib.sha256(oracle.py.stark_flat(oracle.py.mk_stark_proof(w, inp, sp, 64, 8))).hexdigest())
     for rank in (0, 1):
         assert (tmp_path / ("rank%d.txt" % rank)).read_text().split(",") == want
+        assert (tmp_path / ("stark_rank%d.txt" % rank)).read_text().split(",") == swant
 
 
 def test_rare_carry_branches(sa):
