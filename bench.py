@@ -1,24 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- the hot-path benchmark (driver contract: one JSON line on rank 0).
 
-Metric (BASELINE.json): NTT field elements per second.  Workload at every N: BASELINE configs[1] -- a
-2^20-point forward NTT followed by the inverse NTT over the MiMC prime, data resident in HBM, one
-independent vector per GPU (weak scaling, no data-path collective: SURVEY 8(e)).  A "step" = one forward +
-one inverse transform = 2 * 2^20 transformed elements.  `value` = elements of all ranks / max-over-ranks time.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ntt|c5]
 
-Also on the same line:
-  roofline      -- the NTT tile-pass kernel (the dominant kernel): algorithmic bytes (64 B per element per
-                   transform) / HIP-event time of the timed region on the library's stream.
-  cpu_baseline  -- the C oracle (oracle/oracle.c: the reference's recursive algorithm, one core) on a
-                   bounded sample of the same workload, rank 0 at N=1 only.
-  extra         -- 2^24-point NTT (config 4), FRI commit of a 2^14-step (config 3) and a 2^20-step MiMC trace,
-                   Merkle commit of 2^24 leaves: ms, elements/s, field-mul-equivalents/s, algorithmic GB/s.
+Launch.  With --gpus N > 1 and no torch.distributed environment, bench.py starts N ranks itself
+(`python -m torch.distributed.run`, one process per GPU, as a CHILD process and before this process touches the GPU);
+launched by the driver through torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
+
+Workload `ntt` (default; BASELINE.json's metric, configs[1]): a 2^20-point forward NTT followed by the inverse NTT
+over the MiMC prime, data resident in HBM, `--batch` (8) independent vectors per step per GPU -- the columns of a
+trace, one launch sequence covers all of them.  Ranks transform their own vectors: weak scaling, no data-path
+collective.  `value` = transformed elements of all ranks / max-over-ranks time.  The literal single-vector
+configs[1] figure and the metric's second half (FRI commit of a 2^20-step trace) are the top-level keys
+`single_vector_elements_per_s` and `fri_commit_ms_2^20_trace` (rank 0, N = 1).
+
+Workload `c5` (BASELINE configs[4]): `--units` (512) independent 2^16-step MiMC STARK proofs (STARK.mk_proof,
+stark.py:233-279; unit j = test_stark.py:265-293 started from 3 + j), sharded over the ranks by proof index
+(starks_amd/batch.py:shard), 32 proofs per batched launch; a step = the whole batch once; `value` = proofs/s; strong
+scaling; the only exchange is one all_gather of the 64-byte proof headers (m_root | l_root) per step (RCCL).  Every run of
+the default workload also runs one such step after its timed region and reports it under `c5` / `c5_proofs_per_s`, so
+that the driver's N = 1, 2, 4, 8 runs record the proofs/s curve too.
+
+Also on the line:
+  roofline      -- the dominant kernel: algorithmic bytes / HIP-event time of the timed region on the
+                   library's stream.
+  cpu_baseline  -- the C oracle (oracle/oracle.c: the reference's recursive algorithm) on a bounded sample of the same
+                   workload, rank 0 at N = 1 only.
+  extra         -- 2^24-point NTT (config 4), FRI commits, Merkle commit of 2^24 leaves, whole STARK proofs.
 """
 import argparse
 import ctypes
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -68,6 +84,107 @@ class Dev:
         return ms.value / reps
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# config 5: many independent STARK proofs, sharded by proof index
+# ---------------------------------------------------------------------------------------------------------------------
+class ProofShard:
+    """This rank's units of the many-proof workload, resident in HBM: pristine witnesses (generated on the device,
+    untimed), one work buffer per chunk (the prover overwrites its witness), the flat proofs of the whole shard."""
+
+    def __init__(self, dev, units, steps, ext=8, chunk=32):
+        from starks_amd import stark
+        from starks_amd.modp import IntegersModP
+        from starks_amd.multivariate_polynomial import generate_Xi_s
+        self.dev, self.units, self.steps, self.ext, self.chunk = dev, list(units), steps, ext, chunk
+        X1, X2 = generate_Xi_s(IntegersModP(P), 2)
+        self.polys = [X1, X1 + X2**3]
+        self.coefs, self.exps, self.counts, self.degree = stark.pack_step_polys(self.polys, 2)
+        self.plen = stark.proof_len(steps, ext, 2, self.degree)
+        k = max(1, len(self.units))
+        L, ctx = dev.L, dev.ctx
+        self.wbytes = 64 * steps  # one unit's witness: 2 columns
+        self.d_wit = dev.alloc(self.wbytes * k)
+        self.d_inp = dev.alloc(64 * k)
+        self.d_work = dev.alloc(self.wbytes * chunk)
+        self.d_proofs = dev.alloc(self.plen * k)
+        if self.units:  # shards are contiguous ranges (batch.shard)
+            assert self.units == list(range(self.units[0], self.units[0] + len(self.units)))
+            dev.ck(L.sh_dev_fill_mimc_units(ctx, self.d_wit, self.d_inp, steps, self.units[0], len(self.units), 42), "fill units")
+        dev.sync()
+
+    def prove_all(self):
+        """One step: every unit of the shard, `chunk` per launch sequence; asynchronous on the library stream."""
+        dev, L, ctx = self.dev, self.dev.L, self.dev.ctx
+        for c in range(0, len(self.units), self.chunk):
+            k = min(self.chunk, len(self.units) - c)
+            # the prover consumes its witness: take a copy of the pristine one (device to device, part of the step)
+            dev.ck(L.sh_dev_copy(ctx, ctypes.c_void_p(self.d_wit.value + self.wbytes * c), self.d_work, self.wbytes * k), "copy")
+            dev.ck(L.sh_dev_stark_prove(ctx, self.d_work, ctypes.c_void_p(self.d_inp.value + 64 * c), self.steps, self.ext, 2,
+                                        self.coefs, self.exps, self.counts, 80, k,
+                                        ctypes.c_void_p(self.d_proofs.value + self.plen * c)), "stark prove")
+
+    def headers(self):
+        """m_root | l_root of every proof of the shard (64 B each); synchronises; raises on an invalid witness."""
+        k = len(self.units)
+        rc = self.dev.L.sh_stark_status(self.dev.ctx)
+        if rc != 0:
+            self.dev.ck(rc, "stark status")
+        out = ctypes.create_string_buffer(64 * max(k, 1))
+        if k:
+            self.dev.ck(self.dev.L.sh_dev_download_2d(self.dev.ctx, self.d_proofs, self.plen, out, 64, k), "headers")
+        return [out.raw[64 * i:64 * i + 64] for i in range(k)]
+
+    def proof(self, i):
+        out = ctypes.create_string_buffer(self.plen)
+        self.dev.ck(self.dev.L.sh_dev_download(self.dev.ctx, ctypes.c_void_p(self.d_proofs.value + self.plen * i), out, self.plen), "dl")
+        return out.raw
+
+    def close(self):
+        for p in (self.d_wit, self.d_inp, self.d_work, self.d_proofs):
+            self.dev.free(p)
+
+
+def gather_headers(local, total, rank, world, dist, tdev):
+    """all_gather of the fixed-size proof headers (the only exchange of the many-proof path)."""
+    if world == 1:
+        return list(local)
+    import torch
+    from starks_amd.batch import shard
+    width = len(shard(total, 0, world))
+    buf = torch.zeros(width * 64, dtype=torch.uint8, device=tdev)
+    flat = b"".join(local)
+    if flat:
+        buf[:len(flat)] = torch.frombuffer(bytearray(flat), dtype=torch.uint8).to(tdev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = []
+    for r in range(world):
+        raw = parts[r].cpu().numpy().tobytes()
+        out.extend(raw[64 * i:64 * i + 64] for i in range(len(shard(total, r, world))))
+    return out
+
+
+def c5_check(dev, sh, rank):
+    """What was timed is right: a unit proved inside a batch == the same unit proved alone (sh_stark_prove from host
+    buffers), byte for byte; on rank 0 the host verifier (stark.py:281-388) accepts it."""
+    from starks_amd import batch, stark
+    from starks_amd.modp import IntegersModP
+    if not sh.units:
+        return {"batch_equals_single": True, "verifies": None}
+    i = len(sh.units) - 1
+    got = sh.proof(i)
+    w, inp = batch.mimc_stark_unit(sh.units[i], sh.steps)
+    wit = b"".join(b"".join(v.to_bytes(32, "big") for v in col) for col in w)
+    single = stark.prove_flat(wit, b"".join(v.to_bytes(32, "big") for v in inp), sh.steps, sh.ext, 2, sh.polys)
+    res = {"unit": sh.units[i], "batch_equals_single": got == single, "sha256": hashlib.sha256(got).hexdigest(), "verifies": None}
+    if rank == 0:
+        S = stark.STARK(IntegersModP(P), sh.steps, sh.ext, 2, sh.polys)
+        pr = stark.unpack_proof(got, sh.steps, sh.ext, 2, sh.degree)
+        res["verifies"] = bool(S.verify_proof(pr, w, [(0, j, v) for j, v in enumerate(inp)]))
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def extras(dev, quick):
     """Secondary legs, rank 0 at N=1 only (not part of `value`)."""
     L, ctx = dev.L, dev.ctx
@@ -79,7 +196,19 @@ def extras(dev, quick):
         dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
         dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed), "fill")
         ms = dev.timed(lambda: dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"), 10)
-        # size-independent check: inverse brings the input back (digest of both)
+        # reference-independent pin: the forward digest against the C oracle's (tests/golden/ntt_large.json)
+        whole = ctypes.create_string_buffer(32 * n)
+        dev.ck(L.sh_dev_to_wire(ctx, dy, whole, n), "dl")
+        sha = hashlib.sha256(whole.raw).hexdigest()
+        del whole
+        pin = None
+        try:
+            for c in json.load(open(os.path.join(ROOT, "tests", "golden", "ntt_large.json")))["cases"]:
+                if c["n"] == n:
+                    pin = c["sha_fwd"] == sha
+        except Exception:
+            pass
+        # size-independent check: inverse brings the input back
         dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")
         chk = 1 << 16
         a, b = ctypes.create_string_buffer(32 * chk), ctypes.create_string_buffer(32 * chk)
@@ -89,7 +218,7 @@ def extras(dev, quick):
             "ms": round(ms, 4), "elements_per_s": n / ms * 1e3,
             "field_mul_eq_per_s": (n // 2) * logn / ms * 1e3,
             "algorithmic_GBps": 64.0 * n / ms / 1e6, "hbm_frac": 64.0 * n / ms / 1e6 / HBM_PEAK_GBS,
-            "roundtrip_ok": a.raw == b.raw}
+            "roundtrip_ok": a.raw == b.raw, "fwd_sha256_matches_oracle_fixture": pin}
         dev.free(dx)
         dev.free(dy)
     # ---- Merkle commit -----------------------------------------------------------------------------
@@ -111,7 +240,7 @@ def extras(dev, quick):
     out["lde_%dx2^%d_x8" % (cols, steps.bit_length() - 1)] = {"ms": round(ms, 4), "out_elements_per_s": n * cols / ms * 1e3}
     dev.free(dtr)
     dev.free(dout)
-    # ---- config 5 on one GPU: batches of independent 2^16-step proofs (N = 2^19 each) ---------------------------
+    # ---- batches of independent 2^16-step FRI commits (N = 2^19 each) ---------------------------
     steps, ext, bsz = (1 << 12 if quick else 1 << 16), 8, 32
     n = steps * ext
     w = root_of(n).to_bytes(32, "big")
@@ -151,21 +280,14 @@ def extras(dev, quick):
     from starks_amd.modp import IntegersModP
     X1, X2 = generate_Xi_s(IntegersModP(P), 2)
     coefs, exps, counts, degree = _stark.pack_step_polys([X1, X1 + X2**3], 2)
-    for logsteps, bsz in ([(12, 4)] if quick else [(14, 1), (16, 1), (16, 32), (20, 1)]):
+    for logsteps, bsz in ([(12, 4)] if quick else [(14, 1), (16, 1), (20, 1)]):
         steps, ext, width = 1 << logsteps, 8, 2
-        k, x = 42, 3
-        col = [x]
-        for _ in range(steps - 1):
-            x = (x * x * x + k) % P
-            col.append(x)
-        wit = b"".join(v.to_bytes(32, "big") for v in [k] * steps + col) * bsz
-        inp = (k.to_bytes(32, "big") + (3).to_bytes(32, "big")) * bsz
         plen = _stark.proof_len(steps, ext, width, degree)
-        dw, di, dp = dev.alloc(len(wit)), dev.alloc(len(inp)), dev.alloc(plen * bsz)
-        dev.ck(L.sh_dev_from_wire(ctx, inp, di, width * bsz), "inputs")
+        dw0, dw, di, dp = dev.alloc(64 * steps * bsz), dev.alloc(64 * steps * bsz), dev.alloc(64 * bsz), dev.alloc(plen * bsz)
+        dev.ck(L.sh_dev_fill_mimc_units(ctx, dw0, di, steps, 0, bsz, 42), "units")
         best = None
-        for _ in range(4):  # the prover consumes its witness: re-upload (untimed) before every timed call
-            dev.ck(L.sh_dev_from_wire(ctx, wit, dw, width * steps * bsz), "witness")
+        for _ in range(4):  # the prover consumes its witness: restore it (untimed) before every timed call
+            dev.ck(L.sh_dev_copy(ctx, dw0, dw, 64 * steps * bsz), "copy")
             dev.sync()
             dev.ck(L.sh_timer_start(ctx), "timer")
             dev.ck(L.sh_dev_stark_prove(ctx, dw, di, steps, ext, width, coefs, exps, counts, 80, bsz, dp), "stark")
@@ -178,16 +300,14 @@ def extras(dev, quick):
         out["stark_prove_batch%d_steps_2^%d" % (bsz, logsteps)] = {
             "ms_per_batch": round(best, 4), "ms_per_proof": round(best / bsz, 5), "proofs_per_s": bsz / best * 1e3,
             "proof_bytes": plen, "m_root": head.raw[:32].hex()}
-        dev.free(dw)
-        dev.free(di)
-        dev.free(dp)
+        for p_ in (dw0, dw, di, dp):
+            dev.free(p_)
     return out
 
 
 def cpu_baseline(logn, vectors, budget_s=10.0):
     """The C oracle (the reference's algorithm, scalar code) on the same workload: the step's independent vectors are
     spread over host cores, one child process per vector (oracle/cpu_worker.py), at most the cores this box gives us."""
-    import subprocess
     from oracle import coracle
     coracle.build()  # once, before the workers race for it
     n = 1 << logn
@@ -210,28 +330,112 @@ def cpu_baseline(logn, vectors, budget_s=10.0):
             "roundtrip_ok": all(r["roundtrip_ok"] for r in res), "digest": res[0]["fwd_sha256"]}
 
 
+def cpu_baseline_c5(steps, ext=8):
+    """Config 5's CPU baseline: the oracle has no whole-prover in C (the STARK oracle is coefficient-form Python, O(n^2));
+    what it can time at this size is the FRI commit of one unit's trace polynomial (oracle/oracle.c:fri_rec, the
+    reference's algorithm) -- a LOWER bound of one proof's CPU cost, stated as such."""
+    from oracle import coracle, pyoracle
+    coracle.build()
+    g2 = root_of(steps * ext)
+    trace = pyoracle.mimc_trace(3, steps)
+    wire = b"".join(v.to_bytes(32, "big") for v in trace)
+    t0 = time.time()
+    coeffs = coracle.fft_bytes(wire, steps, pow(g2, ext, P), inverse=True)
+    coracle.fri_prove_flat(coeffs, g2, steps, ext, 40)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": "one unit: inverse NTT of the trace + FRI commit (N = %d) with oracle/oracle.c, %.1f s; this is only "
+                      "the FRI part of a proof (a lower bound of the CPU cost: the reference's quotient construction is "
+                      "O(n^2) and not runnable at this size)" % (steps * ext, dt)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """--gpus N > 1 without a launcher: start the N ranks as a child torch.distributed.run (never exec: this process may
+    already have touched the GPU, e.g. under rocprofv3) and hand back its exit code."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """Launcher / sharding / gather plumbing WITHOUT the GPU (CPU tests only; `value` is null and the line says so)."""
+    import torch
+    import torch.distributed as dist
+    from starks_amd.batch import shard
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    mine = shard(args.units, rank, world)
+    t0 = time.perf_counter()
+    local = [hashlib.sha256(b"unit-%d" % j).digest() * 2 for j in mine]  # stand-in headers
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    allh = gather_headers(local, args.units, rank, world, dist, "cpu")
+    ok = allh == [hashlib.sha256(b"unit-%d" % j).digest() * 2 for j in range(args.units)]
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": None, "unit": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True, "data": "none (plumbing only, no GPU work)",
+                          "config": {"workload": args.workload, "units": args.units}, "gather_ok": ok,
+                          "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)]}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--logn", type=int, default=20, help="log2 transform length (configs[1] = 20)")
-    ap.add_argument("--batch", type=int, default=8, help="independent vectors transformed per step (the columns of a "
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50 for ntt, 2 for c5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5 for ntt, 1 for c5)")
+    ap.add_argument("--workload", choices=["ntt", "c5"], default="ntt")
+    ap.add_argument("--logn", type=int, default=20, help="ntt: log2 transform length (configs[1] = 20)")
+    ap.add_argument("--batch", type=int, default=8, help="ntt: independent vectors transformed per step (the columns of a "
                     "trace: one launch sequence covers all of them)")
+    ap.add_argument("--units", type=int, default=None, help="c5: proofs in the batch (512; 16 with --quick)")
+    ap.add_argument("--logsteps", type=int, default=None, help="c5: log2 trace length (16; 10 with --quick)")
+    ap.add_argument("--chunk", type=int, default=32, help="c5: proofs per batched launch")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--quick", action="store_true", help="smaller secondary legs")
+    ap.add_argument("--no-c5", action="store_true", help="ntt: skip the many-proof leg")
+    ap.add_argument("--quick", action="store_true", help="smaller secondary legs / c5 shape")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                     "the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU tests: launcher, sharding and gather only -- no GPU work, "
+                    "value = null")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.workload == "ntt" else 2
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == "ntt" else 1
+    if args.units is None:
+        args.units = 16 if args.quick else 512
+    if args.logsteps is None:
+        args.logsteps = 10 if args.quick else 16
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # before torch / HIP are touched in this process
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        sys.exit(dry_run(args, rank, world))
 
     import torch
     import torch.distributed as dist
+    from starks_amd.batch import shard
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     os.environ["STARKHIP_DEVICE"] = str(dev_index)
@@ -245,6 +449,91 @@ def main():
 
     dev = Dev()
     L, ctx = dev.L, dev.ctx
+
+    def fence():
+        dev.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], device=tdev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def run_c5(steps_k, warm_k):
+        """K timed steps of the many-proof workload; returns the result dict (rank-independent fields agree on all ranks)."""
+        steps = 1 << args.logsteps
+        mine = shard(args.units, rank, world)
+        sh = ProofShard(dev, mine, steps, 8, args.chunk)
+        heads = None
+        for _ in range(warm_k):
+            sh.prove_all()
+            gather_headers(sh.headers(), args.units, rank, world, dist, tdev)
+        fence()
+        dev.ck(L.sh_timer_start(ctx), "timer")
+        t0 = time.perf_counter()
+        for _ in range(steps_k):
+            sh.prove_all()
+            heads = gather_headers(sh.headers(), args.units, rank, world, dist, tdev)  # the step's only exchange
+        ev = ctypes.c_float()
+        dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev)), "timer")
+        fence()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        chk = c5_check(dev, sh, rank)
+        ok = all_ok(chk["batch_equals_single"] and chk["verifies"] is not False and len(set(heads)) == len(heads))
+        n = steps * 8
+        res = {"units": args.units, "trace_steps": steps, "domain": n, "proofs_per_launch": args.chunk,
+               "proofs_per_s": args.units * steps_k / dt, "ms_per_step": dt / steps_k * 1e3, "ms_per_proof": dt / steps_k / args.units * 1e3,
+               "n_gpus": world, "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)],
+               "proof_bytes": sh.plen, "headers_sha256": hashlib.sha256(b"".join(heads)).hexdigest(),
+               "rank0_event_ms_per_step": ev.value / steps_k,
+               "check": {"ok": ok, "rank0": chk}}
+        sh.close()
+        return res
+
+    # =================================================================================================================
+    if args.workload == "c5":
+        res = run_c5(args.steps, args.warmup)
+        steps = 1 << args.logsteps
+        n = steps * 8
+        # algorithmic bytes of one proof (SURVEY 8(d) per-unit figures): per column LDE 64 (s + N) + 64 s, quotients /
+        # leaves / combination read and write each evaluation array once more (DESIGN.md section 5), FRI 203 N
+        alg = 2 * (64.0 * (2 * steps + n)) + (96.0 * 2 + 64.0 * 2 + 96.0 * 2 + 96.0 * 2 + 32.0) * n + (203.0 - 64.0) * n
+        achieved = alg * len(shard(args.units, rank, world)) / (res["rank0_event_ms_per_step"] * 1e-3) / 1e9
+        line = {
+            "metric": "stark_proofs_per_sec", "value": res["proofs_per_s"], "unit": "proofs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU)", "data": "synthetic",
+            "config": {"workload": "configs[4]: batch of %d independent 2^%d-step MiMC STARK proofs (STARK.mk_proof, width 2, "
+                                   "8x extension, 80 spot checks, FRI 40 samples), sharded by proof index over %d GPU(s), %d "
+                                   "proofs per batched launch; a step proves the whole batch once" %
+                                   (args.units, args.logsteps, world, args.chunk),
+                       "units": args.units, "trace_steps": steps, "parallelism": "proof sharding x%d" % world},
+            "c5": res, "c5_proofs_per_s": res["proofs_per_s"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole proof (NTT passes ~30 %, packed-leaf hashing ~18 %, quotients ~20 %: DESIGN.md section 5)",
+                         "algorithmic_bytes_per_proof": alg,
+                         "note": "integer-VALU / BLAKE2s-ALU bound, not HBM bound"},
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_c5(steps)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- workload ntt ---------------------------------------------------------------------------------------------------
     n = 1 << args.logn
     w = root_of(n).to_bytes(32, "big")
     B = max(1, args.batch)
@@ -256,13 +545,6 @@ def main():
         dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, B, w, 0), "ntt")   # y = NTT(x), every vector
         dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, B, w, 1), "intt")  # y = invNTT(y) == x
 
-    def fence():
-        dev.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     fence()
@@ -273,11 +555,7 @@ def main():
     ev_ms = ctypes.c_float()
     dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev_ms)), "timer")  # HIP events on the library's stream
     fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    dt_max = max_over_ranks(time.perf_counter() - t0)
 
     # correctness of what was timed: x == invNTT(NTT(x)) and the forward digest against the fixture (rank 0)
     a, b = ctypes.create_string_buffer(32 * n * B), ctypes.create_string_buffer(32 * n * B)
@@ -295,23 +573,23 @@ def main():
             golden_ok = hit[0]["sha_fwd"] == fwd_digest
     except Exception:
         pass
-    ok = torch.tensor([1 if roundtrip_ok and golden_ok is not False else 0], device=tdev)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the only exchange: a 1-word status gather over RCCL
+    ok = all_ok(roundtrip_ok and golden_ok is not False)  # the only exchange: a 1-word status gather over RCCL
 
     elems_per_step = 2 * n * B
     value = elems_per_step * args.steps * world / dt_max
     alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
     achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_traffic.sh)
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if args.logn == 20 and tj.get("vectors_per_step", 1) == B:
-            traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)"
-    except Exception:
-        pass
-    passes = 1 if args.logn <= 8 else (args.logn + 7) // 8
+    for tf in ("r02_traffic.json", "r01_traffic.json"):
+        try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_traffic.sh)
+            tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+            if args.logn == 20 and tj.get("vectors_per_step", 1) == B:
+                traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
+                traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)" % tf
+                break
+        except Exception:
+            pass
+    passes = int(L.sh_ntt_passes(n))
     line = {
         "metric": "ntt_field_elements_per_sec", "value": value, "unit": "elements/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
@@ -319,33 +597,47 @@ def main():
         "data": "synthetic", "config": {
             "workload": "configs[1]: 2^%d-point NTT + inverse NTT over the MiMC prime, %d independent vectors per step "
                         "per GPU (the columns of a trace, one launch sequence), x == invNTT(NTT(x)) checked on all; "
-                        "the single-vector figure is extra.ntt_2^%d_single_vector" % (args.logn, B, args.logn),
+                        "the single-vector figure is single_vector_elements_per_s" % (args.logn, B),
             "n": n, "vectors_per_step": B, "elements_per_step": elems_per_step,
             "parallelism": "independent vectors x%d" % world},
         "field_mul_eq_per_s": (n // 2) * args.logn * 2 * B * args.steps * world / dt_max,
-        "check": {"roundtrip_ok": bool(int(ok.item())), "fwd_sha256": fwd_digest, "matches_reference_fixture": golden_ok},
+        "check": {"roundtrip_ok": ok, "fwd_sha256": fwd_digest, "matches_reference_fixture": golden_ok},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 64.0 * n * B / passes,
                      "kernel": "ntt_pass_kernel (%d launches per 2^%d transform)" % (passes, args.logn),
                      "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
-                     "note": "integer-VALU bound, not HBM bound: ~11 256-bit modmuls + 20 add/sub per element per "
-                             "transform at ~95% of the half-rate VALU issue ceiling; see DESIGN.md section 5"},
+                     "note": "integer-VALU bound, not HBM bound; see DESIGN.md section 5"},
     }
+    single_ms = None
+    if rank == 0 and world == 1:
+        # the literal configs[1]: the same transform pair on ONE vector (a launch's load / store phases are then exposed)
+        single_ms = dev.timed(lambda: (dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"),
+                                       dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")), 50)
+        line["single_vector_elements_per_s"] = 2 * n / single_ms * 1e3
+        line["single_vector_ms_per_fwd_inv"] = round(single_ms, 5)
+    dev.free(dx)
+    dev.free(dy)
+    if not args.no_c5:
+        # one step of the many-proof workload over the same ranks (after one warm-up step): the proofs/s curve
+        res = run_c5(1, 1)
+        line["c5"] = res
+        line["c5_proofs_per_s"] = res["proofs_per_s"]
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.logn, B)
             line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
         if not args.no_extras:
             line["extra"] = extras(dev, args.quick)
-            # the same transform pair on ONE vector (a launch's load / store phases are then exposed: nothing else runs)
-            single = dev.timed(lambda: (dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"),
-                                        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")), 50)
-            line["extra"]["ntt_2^%d_single_vector" % args.logn] = {
-                "ms_per_fwd_inv": round(single, 5), "elements_per_s": 2 * n / single * 1e3}
-    dev.free(dx)
-    dev.free(dy)
+            k20 = "fri_commit_steps_2^20"
+            if k20 in line["extra"]:
+                line["fri_commit_ms_2^20_trace"] = line["extra"][k20]["ms"]
+            line["fri_commit_ms_2^14_trace"] = line["extra"]["fri_commit_steps_2^14"]["ms"]
+            big = [k for k in line["extra"] if k.startswith("ntt_2^")]
+            if big:
+                line["ntt_large_elements_per_s"] = line["extra"][big[0]]["elements_per_s"]
+                line["ntt_large_hbm_frac"] = line["extra"][big[0]]["hbm_frac"]
     if rank == 0:
         print(json.dumps(line))
     if world > 1:

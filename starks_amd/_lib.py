@@ -72,6 +72,9 @@ def lib():
         "sh_dev_to_wire": (i32, [c_p, c_p, c_p, u64]),
         "sh_dev_download": (i32, [c_p, c_p, c_p, u64]),
         "sh_dev_upload": (i32, [c_p, u8p, c_p, u64]),
+        "sh_dev_copy": (i32, [c_p, c_p, c_p, u64]),
+        "sh_ntt_passes": (u32, [u64]),
+        "sh_dev_download_2d": (i32, [c_p, c_p, u64, c_p, u64, u64]),
         "sh_dev_fill_seeded": (i32, [c_p, c_p, u64, u64]),
         "sh_dev_ntt": (i32, [c_p, c_p, c_p, u64, u32, u8p, i32]),
         "sh_dev_lde": (i32, [c_p, c_p, c_p, u64, u32, u32, u8p]),
@@ -82,6 +85,9 @@ def lib():
         "sh_stark_prove": (i32, [c_p, u8p, u8p, u64, u32, u32, u8p, u8p, c_p, u32, u32, c_p, u64]),
         "sh_dev_stark_prove": (i32, [c_p, c_p, c_p, u64, u32, u32, u8p, u8p, c_p, u32, u32, c_p]),
         "sh_stark_status": (i32, [c_p]),
+        "sh_stark_status_batch": (i32, [c_p, c_p, u32]),
+        "sh_ctx_trim": (i32, [c_p]),
+        "sh_dev_fill_mimc_units": (i32, [c_p, c_p, c_p, u64, u32, u32, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the library does not export what the header declares

@@ -92,5 +92,79 @@ def prove_stark_batch(unit_ids, steps, ext=8, chunk=16):
     return out
 
 
+def prove_stark_units_device(first_unit, count, steps, ext=8, chunk=32, keep=None, constant=42):
+    """BASELINE configs[4] on this process's GPU with device-resident data: the STARK proofs of units first_unit ..
+    first_unit + count - 1 (`mimc_stark_unit`), `chunk` proofs per batched launch.  Witnesses are generated on the device
+    (sh_dev_fill_mimc_units), proofs stay on the device and only their SHA-256 digests come back -- unless `keep` is a set of
+    unit ids whose flat proofs are returned too.  -> (digests in unit order, {unit: flat proof}).
+
+    This is what bench.py --workload c5 times; `StarkUnitProver` below exposes the pieces so that generation can stay untimed."""
+    pr = StarkUnitProver(steps, ext, chunk, constant)
+    try:
+        digs, kept = [], {}
+        for c in range(0, count, chunk):
+            k = min(chunk, count - c)
+            pr.generate(first_unit + c, k)
+            pr.prove(k)
+            flats = pr.download(k)
+            for i, flat in enumerate(flats):
+                digs.append(digest(flat))
+                if keep and first_unit + c + i in keep:
+                    kept[first_unit + c + i] = flat
+        return digs, kept
+    finally:
+        pr.close()
+
+
+class StarkUnitProver(object):
+    """Device buffers for `chunk` MiMC STARK units of `steps` steps: generate() fills witnesses and inputs on the device,
+    prove() launches sh_dev_stark_prove on them (asynchronous), status()/download() synchronise."""
+
+    def __init__(self, steps, ext=8, chunk=32, constant=42):
+        import ctypes
+        from . import _lib, stark
+        from .modp import IntegersModP
+        from .multivariate_polynomial import generate_Xi_s
+        self._lib, self.L, self.ctx = _lib, _lib.lib(), _lib.ctx()
+        self.steps, self.ext, self.chunk, self.constant = steps, ext, chunk, constant
+        X1, X2 = generate_Xi_s(IntegersModP(MIMC_P), 2)
+        self.coefs, self.exps, self.counts, self.degree = stark.pack_step_polys([X1, X1 + X2**3], 2)
+        self.plen = stark.proof_len(steps, ext, 2, self.degree)
+        if self.plen == 0:
+            raise NotImplementedError("unsupported shape (steps=%d, ext=%d)" % (steps, ext))
+        self.dw, self.di, self.dp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        for ptr, nbytes in ((self.dw, 64 * steps * chunk), (self.di, 64 * chunk), (self.dp, self.plen * chunk)):
+            _lib.check(self.L.sh_dev_alloc(self.ctx, nbytes, ctypes.byref(ptr)), "sh_dev_alloc")
+
+    def generate(self, first_unit, k):
+        self._lib.check(self.L.sh_dev_fill_mimc_units(self.ctx, self.dw, self.di, self.steps, first_unit, k, self.constant),
+                        "sh_dev_fill_mimc_units")
+
+    def prove(self, k):
+        """The prover overwrites its witness: generate() again before the next prove()."""
+        self._lib.check(self.L.sh_dev_stark_prove(self.ctx, self.dw, self.di, self.steps, self.ext, 2, self.coefs, self.exps,
+                                                  self.counts, 80, k, self.dp), "sh_dev_stark_prove")
+
+    def status(self):
+        rc = self.L.sh_stark_status(self.ctx)
+        if rc == -8:
+            raise AssertionError("a witness of the batch is not a valid trace")
+        self._lib.check(rc, "sh_stark_status")
+
+    def download(self, k):
+        import ctypes
+        self.status()
+        out = ctypes.create_string_buffer(self.plen * k)
+        self._lib.check(self.L.sh_dev_download(self.ctx, self.dp, out, self.plen * k), "sh_dev_download")
+        raw = out.raw
+        return [raw[i * self.plen:(i + 1) * self.plen] for i in range(k)]
+
+    def close(self):
+        for ptr in (self.dw, self.di, self.dp):
+            if ptr:
+                self.L.sh_dev_free(self.ctx, ptr)
+        self.dw = self.di = self.dp = None
+
+
 def digest(proof_bytes):
     return hashlib.sha256(proof_bytes).digest()

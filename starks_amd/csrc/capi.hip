@@ -110,7 +110,8 @@ struct sh_ctx {
   void* terms_dev = nullptr;   // [terms][derivative terms]: see TermLayout
   uint32_t terms_begin[SHK_STARK_MAX_WIDTH + 1] = {};
   uint32_t terms_degree = 0;
-  uint32_t* bad_flag = nullptr;
+  uint32_t* bad_flag = nullptr;  // [bad_cap] per-proof constraint flags of the calls since the last sh_stark_status*
+  uint32_t bad_cap = 0;
 };
 
 namespace {
@@ -260,6 +261,37 @@ void choose_radices(int log_n, std::vector<int>* out) {
   }
   const int m = (log_n + 7) / 8, base = log_n / m, rem = log_n % m;
   for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));
+}
+
+constexpr size_t MAX_PLANS = 96;  // twiddle-table sets kept per ctx before the caches are dropped (sh_ctx_trim)
+
+// Free every cached table (NTT plans, the STARK prover's inverse tables) and the workspaces, after the stream drained.
+// Everything is rebuilt on demand.
+int trim(sh_ctx* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& kv : c->plans) {
+    for (void* p : kv.second->owned) (void)hipFree(p);
+    delete kv.second;
+  }
+  c->plans.clear();
+  for (auto& kv : c->inv_z2) (void)hipFree(kv.second);
+  c->inv_z2.clear();
+  for (auto& kv : c->inv_omega) (void)hipFree(kv.second);
+  c->inv_omega.clear();
+  for (int i = 0; i < sh_ctx::WS_COUNT; ++i) {
+    if (c->ws[i]) (void)hipFree(c->ws[i]);
+    c->ws[i] = nullptr;
+    c->ws_cap[i] = 0;
+  }
+  return SH_OK;
+}
+
+// Called on entry of every public function that builds plans, never while a plan pointer is held: a long-lived prover
+// that meets many shapes must not grow for ever (a call creates at most 4 plans).
+int enter(sh_ctx* c) {
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->plans.size() + 4 > MAX_PLANS) SH_TRY(trim(c));
+  return SH_OK;
 }
 
 std::string plan_key(const fp& root, uint64_t n, bool scaled) {
@@ -607,6 +639,26 @@ int stark_terms(sh_ctx* c, uint32_t width, const uint8_t* coefs, const uint8_t* 
   return SH_OK;
 }
 
+// per-proof constraint flags: grown (and zeroed) on demand; flags already raised survive a growth
+int bad_flags(sh_ctx* c, uint32_t batch) {
+  if (batch <= c->bad_cap) return SH_OK;
+  const uint32_t cap = (batch + 63u) & ~63u;
+  uint32_t* nf = nullptr;
+  HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&nf), (size_t)cap * 4));
+  hipError_t e = hipMemsetAsync(nf, 0, (size_t)cap * 4, c->stream);
+  if (e == hipSuccess && c->bad_flag)
+    e = hipMemcpyAsync(nf, c->bad_flag, (size_t)c->bad_cap * 4, hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(nf);
+    HIP_TRY(c, e);
+  }
+  if (c->bad_flag) (void)hipFree(c->bad_flag);
+  c->bad_flag = nf;
+  c->bad_cap = cap;
+  return SH_OK;
+}
+
 int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t ext, uint32_t width, uint32_t samples,
               uint32_t batch, uint8_t* d_proof) {
   const uint32_t degree = c->terms_degree;
@@ -638,10 +690,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   fp* iab = reinterpret_cast<fp*>(small);
   fp* scal = reinterpret_cast<fp*>(reinterpret_cast<uint8_t*>(small) + iab_bytes);
   uint32_t* ys = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(small) + iab_bytes + scal_bytes);
-  if (!c->bad_flag) {
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->bad_flag), 64));
-    HIP_TRY(c, hipMemsetAsync(c->bad_flag, 0, 64, c->stream));
-  }
+  SH_TRY(bad_flags(c, batch));
   // cached inverses: 1 / ((x_i - 1)(x_i - x_last)) over the domain, 1 / (omega^j - 1) for the ext-th roots of unity
   // omega^j = x^steps
   fp* inv_z2 = nullptr;
@@ -651,9 +700,13 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
     if (it == c->inv_z2.end()) {
       void* t = nullptr;
       HIP_TRY(c, hipMalloc(&t, n * sizeof(fp)));
-      c->inv_z2[key] = t;
       inv_z2 = reinterpret_cast<fp*>(t);
-      HIP_TRY(c, shk_stark_inv_z2(inv_z2, n, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, x_last, c->stream));
+      const hipError_t e = shk_stark_inv_z2(inv_z2, n, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, x_last, c->stream);
+      if (e != hipSuccess) {  // never cache a table whose fill did not launch
+        (void)hipFree(t);
+        HIP_TRY(c, e);
+      }
+      c->inv_z2[key] = t;
     } else {
       inv_z2 = reinterpret_cast<fp*>(it->second);
     }
@@ -672,8 +725,12 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
       }
       void* t = nullptr;
       HIP_TRY(c, hipMalloc(&t, ext * sizeof(fp)));
+      const hipError_t e = hipMemcpy(t, host.data(), ext * sizeof(fp), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(t);
+        HIP_TRY(c, e);
+      }
       c->inv_omega[key] = t;
-      HIP_TRY(c, hipMemcpy(t, host.data(), ext * sizeof(fp), hipMemcpyHostToDevice));
       inv_omega = reinterpret_cast<fp*>(t);
     } else {
       inv_omega = reinterpret_cast<fp*>(it->second);
@@ -793,14 +850,7 @@ void sh_ctx_destroy(sh_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (auto& kv : c->plans) {
-    for (void* p : kv.second->owned) (void)hipFree(p);
-    delete kv.second;
-  }
-  for (int i = 0; i < sh_ctx::WS_COUNT; ++i)
-    if (c->ws[i]) (void)hipFree(c->ws[i]);
-  for (auto& kv : c->inv_z2) (void)hipFree(kv.second);
-  for (auto& kv : c->inv_omega) (void)hipFree(kv.second);
+  (void)trim(c);
   if (c->terms_dev) (void)hipFree(c->terms_dev);
   if (c->bad_flag) (void)hipFree(c->bad_flag);
   for (int i = 0; i < 2; ++i) {
@@ -862,6 +912,21 @@ int sh_dev_download(sh_ctx* c, const void* d_src, void* host_dst, uint64_t bytes
   HIP_TRY(c, hipSetDevice(c->device));
   return d2h(c, host_dst, d_src, bytes);
 }
+int sh_dev_copy(sh_ctx* c, const void* d_src, void* d_dst, uint64_t bytes) {
+  if (!c || (bytes && (!d_src || !d_dst))) return SH_ERR_INVALID;
+  if (!bytes) return SH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return SH_OK;
+}
+int sh_dev_download_2d(sh_ctx* c, const void* d_src, uint64_t src_pitch, void* host_dst, uint64_t width, uint64_t rows) {
+  if (!c || !d_src || !host_dst || width > src_pitch) return SH_ERR_INVALID;
+  if (!width || !rows) return SH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy2DAsync(host_dst, width, d_src, src_pitch, width, rows, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return SH_OK;
+}
 int sh_dev_from_wire(sh_ctx* c, const uint8_t* host_wire, void* d_limbs, uint64_t n) {
   if (!c || (n && (!host_wire || !d_limbs))) return SH_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -889,14 +954,14 @@ int sh_dev_fill_seeded(sh_ctx* c, void* d_limbs, uint64_t n, uint64_t seed) {
 int sh_dev_ntt(sh_ctx* c, const void* d_in, void* d_out, uint64_t n, uint32_t batch, const uint8_t root[32],
                int inverse) {
   if (!c || !d_in || !d_out || !root) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
   return run_ntt(c, pl, reinterpret_cast<const fp*>(d_in), reinterpret_cast<fp*>(d_out), batch);
 }
 int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t ext, uint32_t cols, const uint8_t g2[32]) {
   if (!c || !d_trace || !d_out || !g2 || cols == 0 || !is_pow2(steps) || !is_pow2(ext)) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   const uint64_t n = steps * ext;
   NttPlan *inv1 = nullptr, *fwd2 = nullptr;
   SH_TRY(plan_for(c, g2, n, false, &fwd2));
@@ -918,7 +983,7 @@ int sh_dev_merkelize(sh_ctx* c, const void* d_values, uint64_t n, uint32_t batch
 int sh_dev_fri_fold(sh_ctx* c, const void* d_values, const void* d_nodes, uint64_t n, uint32_t batch,
                     const uint8_t root[32], void* d_column) {
   if (!c || !d_values || !d_nodes || !d_column || !root || n < 4) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, false, &pl));
   FoldArgs fa;
@@ -941,7 +1006,7 @@ int sh_dev_fri_fold(sh_ctx* c, const void* d_values, const void* d_nodes, uint64
 int sh_dev_fri_prove(sh_ctx* c, const void* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
                      uint32_t exclude, uint32_t samples, uint32_t batch, void* d_proof) {
   if (!c || !root) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   return run_fri(c, reinterpret_cast<const fp*>(d_coeffs), n, root, maxdeg_plus_1, exclude, samples, batch,
                  reinterpret_cast<uint8_t*>(d_proof));
 }
@@ -976,7 +1041,7 @@ int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint
                  const uint8_t root[32], int inverse) {
   if (!c || !out || !root || (n_in && !in) || batch == 0) return SH_ERR_INVALID;
   if (n_in > n) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
   fp* x = nullptr;
@@ -991,7 +1056,7 @@ int sh_ntt(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t n
 int sh_mul_polys(sh_ctx* c, const uint8_t* a, uint64_t n_a, const uint8_t* b, uint64_t n_b, uint8_t* out, uint64_t n,
                  const uint8_t root[32]) {
   if (!c || !out || !root || (n_a && !a) || (n_b && !b) || n_a > n || n_b > n) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   NttPlan *fwd = nullptr, *rev = nullptr;
   SH_TRY(plan_for(c, root, n, false, &fwd));
   SH_TRY(get_plan(c, h_pow(fwd->root, n - 1), n, false, &rev));  // reversed roots, NO 1/n (fft.py:345)
@@ -1007,7 +1072,7 @@ int sh_mul_polys(sh_ctx* c, const uint8_t* a, uint64_t n_a, const uint8_t* b, ui
 
 int sh_power_cycle(sh_ctx* c, const uint8_t root[32], uint64_t n, uint8_t* out) {
   if (!c || !out || !root) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, false, &pl));
   void* x = nullptr;
@@ -1019,7 +1084,7 @@ int sh_power_cycle(sh_ctx* c, const uint8_t root[32], uint64_t n, uint8_t* out) 
 int sh_lde(sh_ctx* c, const uint8_t* trace, uint8_t* out, uint64_t steps, uint32_t ext, uint32_t cols,
            const uint8_t g2[32]) {
   if (!c || !trace || !out || !g2 || cols == 0 || !is_pow2(steps) || !is_pow2(ext)) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   const uint64_t n = steps * ext;
   NttPlan *inv1 = nullptr, *fwd2 = nullptr;
   SH_TRY(plan_for(c, g2, n, false, &fwd2));
@@ -1065,7 +1130,7 @@ int sh_merkelize_packed(sh_ctx* c, const uint8_t* evals, uint64_t n, uint32_t k,
 int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root[32], const uint8_t special_x[32],
                 uint8_t* column) {
   if (!c || !values || !root || !special_x || !column || !is_pow2(n) || n < 4) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, false, &pl));
   fp* v = nullptr;
@@ -1092,6 +1157,13 @@ int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root
   return download_wire(c, reinterpret_cast<fp*>(col), column, n / 4);
 }
 
+uint32_t sh_ntt_passes(uint64_t n) {
+  if (!is_pow2(n) || n > (1ull << 32)) return 0;
+  std::vector<int> r;
+  choose_radices(ilog2(n), &r);
+  return (uint32_t)r.size();
+}
+
 uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
   return fri_proof_len(n, maxdeg_plus_1, samples);
 }
@@ -1100,7 +1172,7 @@ int sh_fri_prove(sh_ctx* c, const uint8_t* coeffs, uint64_t n_coeffs, uint64_t n
                  uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* proof,
                  uint64_t proof_cap) {
   if (!c || !root || !proof || (n_coeffs && !coeffs) || batch == 0 || n_coeffs > n || !is_pow2(n)) return SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   const uint64_t stride = fri_proof_len(n, maxdeg_plus_1, samples);
   if (proof_cap < stride * batch) return SH_ERR_TOO_SMALL;
   fp* x = nullptr;
@@ -1117,23 +1189,46 @@ uint64_t sh_stark_proof_len(uint64_t steps, uint32_t ext, uint32_t width, uint32
   return stark_header_len(n, width, samples) + fri_proof_len(n, steps * (uint64_t)degree, 40);
 }
 
-int sh_stark_status(sh_ctx* c) {
-  if (!c) return SH_ERR_INVALID;
+int sh_stark_status_batch(sh_ctx* c, uint8_t* bad, uint32_t batch) {
+  if (!c || (batch && !bad)) return SH_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (bad) memset(bad, 0, batch);
   if (!c->bad_flag) return SH_OK;
-  uint32_t flag = 0;
-  HIP_TRY(c, hipMemcpy(&flag, c->bad_flag, 4, hipMemcpyDeviceToHost));
-  if (!flag) return SH_OK;
-  HIP_TRY(c, hipMemset(c->bad_flag, 0, 4));
+  std::vector<uint32_t> flags(c->bad_cap);
+  HIP_TRY(c, hipMemcpy(flags.data(), c->bad_flag, (size_t)c->bad_cap * 4, hipMemcpyDeviceToHost));
+  bool any = false;
+  for (uint32_t b = 0; b < c->bad_cap; ++b) {
+    if (!flags[b]) continue;
+    any = true;
+    if (b < batch) bad[b] = 1;
+  }
+  if (!any) return SH_OK;
+  HIP_TRY(c, hipMemset(c->bad_flag, 0, (size_t)c->bad_cap * 4));
   return SH_ERR_CONSTRAINT;
+}
+int sh_stark_status(sh_ctx* c) { return sh_stark_status_batch(c, nullptr, 0); }
+
+int sh_ctx_trim(sh_ctx* c) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return trim(c);
+}
+
+int sh_dev_fill_mimc_units(sh_ctx* c, void* d_witness, void* d_inputs, uint64_t steps, uint32_t first_unit, uint32_t batch,
+                           uint32_t constant) {
+  if (!c || !d_witness || !d_inputs || steps == 0 || batch == 0) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, shk_fill_mimc_units(reinterpret_cast<fp*>(d_witness), reinterpret_cast<fp*>(d_inputs), steps, first_unit, batch,
+                                 constant, c->stream));
+  return SH_OK;
 }
 
 int sh_dev_stark_prove(sh_ctx* c, void* d_witness, const void* d_inputs, uint64_t steps, uint32_t ext, uint32_t width,
                        const uint8_t* term_coefs, const uint8_t* term_exps, const uint32_t* term_counts, uint32_t samples,
                        uint32_t batch, void* d_proof) {
   if (!c || width == 0 || width > SHK_STARK_MAX_WIDTH) return c && width > SHK_STARK_MAX_WIDTH ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   SH_TRY(stark_terms(c, width, term_coefs, term_exps, term_counts));
   return run_stark(c, reinterpret_cast<fp*>(d_witness), reinterpret_cast<const fp*>(d_inputs), steps, ext, width, samples,
                    batch, reinterpret_cast<uint8_t*>(d_proof));
@@ -1144,7 +1239,7 @@ int sh_stark_prove(sh_ctx* c, const uint8_t* witness, const uint8_t* inputs, uin
                    uint32_t batch, uint8_t* proof, uint64_t proof_cap) {
   if (!c || !witness || !inputs || !proof || batch == 0 || width == 0) return SH_ERR_INVALID;
   if (width > SHK_STARK_MAX_WIDTH) return SH_ERR_UNSUPPORTED;
-  HIP_TRY(c, hipSetDevice(c->device));
+  SH_TRY(enter(c));
   SH_TRY(stark_terms(c, width, term_coefs, term_exps, term_counts));
   SH_TRY(stark_check_shape(steps, ext, width, c->terms_degree, samples));
   const uint64_t n = steps * ext;
@@ -1156,6 +1251,8 @@ int sh_stark_prove(sh_ctx* c, const uint8_t* witness, const uint8_t* inputs, uin
   SH_TRY(upload_padded(c, inputs, 1, 1, (uint32_t)cols, sh_ctx::WS_Y, &in));
   void* dp = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_PROOF, (size_t)stride * batch, &dp));
+  // this call reports on its own witnesses only: flags left by unchecked sh_dev_stark_prove calls are dropped
+  if (c->bad_flag) HIP_TRY(c, hipMemsetAsync(c->bad_flag, 0, (size_t)c->bad_cap * 4, c->stream));
   SH_TRY(run_stark(c, w, in, steps, ext, width, samples, batch, reinterpret_cast<uint8_t*>(dp)));
   SH_TRY(d2h(c, proof, dp, (size_t)stride * batch));
   return sh_stark_status(c);

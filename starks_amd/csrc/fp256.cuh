@@ -11,7 +11,8 @@
 // field(b'\xff'*32) (modp.py:33-34) are safe.
 //
 // All functions are __host__ __device__: the same code builds the twiddle tables on the host and is
-// unit-tested on the CPU (tests/test_fp256_host.py) against the oracle.
+// exercised on the CPU through the table builders; the device code is pinned by tests/test_gpu_parity.py
+// (test_rare_carry_branches, the NTT / FRI / STARK parity tests) against the oracle.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -34,6 +34,8 @@ constexpr int SHK_TILE_LOG = 10;  // default tile: 1024 elements (32 KiB of LDS,
 hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st);
 hipError_t shk_limb_to_wire(const fp* d_limbs, uint8_t* d_wire, uint64_t n, hipStream_t st);
 hipError_t shk_fill_seeded(fp* d, uint64_t n, uint64_t seed, hipStream_t st);
+hipError_t shk_fill_mimc_units(fp* wit, fp* inputs, uint64_t steps, uint32_t first_unit, uint32_t batch, uint32_t constant,
+                               hipStream_t st);
 hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipStream_t st);
 // out[i] = g^i for i < n, g given by its two-level table (lo, hi, lb)
 hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st);
@@ -111,7 +113,7 @@ struct StarkArgs {
   fp g1;              // G2^ext = 1 / x_last
   fp inv_steps;       // 1 / steps
   fp inv_1_m_last;    // 1 / (1 - x_last)
-  uint32_t* bad;      // set to 1 when a transition constraint fails on the trace
+  uint32_t* bad;      // [batch] bad[b] is set to 1 when a transition constraint of proof b fails on the trace
   // step polynomials: term t = coef[t] * prod_v X_v^exps[t][v] (exps rows are width + 1 bytes: the last one flags
   // coef == 1); terms of dimension c: [term_begin[c], term_begin[c+1])
   const fp* term_coef;

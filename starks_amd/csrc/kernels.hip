@@ -53,6 +53,26 @@ __global__ void __launch_bounds__(TPB) fill_seeded_kernel(fp* out, uint64_t n, u
   b2digest d = b2_hash_short(m, 16);
   fp_store(out + i, fp_canon(fp_from_wire_words(d.h)));
 }
+// Synthetic many-proof workload (BASELINE configs[4]): unit j of the reference's MiMC formulation (test_stark.py:265-293,
+// utils.py:20-27): width 2, dimension 0 carries the round constant k, dimension 1 the state x <- x^3 + k started from
+// 3 + j.  One thread per unit walks its trace (the recurrence is sequential); witness [batch][2][steps], inputs [batch][2].
+__global__ void __launch_bounds__(64) fill_mimc_units_kernel(fp* wit, fp* inputs, uint64_t steps, uint32_t first_unit,
+                                                            uint32_t batch, uint32_t constant) {
+  const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= batch) return;
+  const fp k = fp_from_u32(constant);
+  fp x = fp_canon(fp_add(fp_from_u32(3u), fp_from_u32(first_unit + b)));
+  fp_store(inputs + 2ull * b, k);
+  fp_store(inputs + 2ull * b + 1, x);
+  fp* c0 = wit + (uint64_t)b * 2 * steps;
+  fp* c1 = c0 + steps;
+#pragma unroll 1
+  for (uint64_t i = 0; i < steps; ++i) {
+    fp_store(c0 + i, k);
+    fp_store(c1 + i, x);
+    x = fp_canon(fp_add(fp_mul(fp_sqr(x), x), k));
+  }
+}
 __global__ void __launch_bounds__(TPB) pointwise_mul_kernel(const fp* a, const fp* b, fp* out, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
@@ -408,6 +428,13 @@ hipError_t shk_limb_to_wire(const fp* d_limbs, uint8_t* d_wire, uint64_t n, hipS
 hipError_t shk_fill_seeded(fp* d, uint64_t n, uint64_t seed, hipStream_t st) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(fill_seeded_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, d, n, seed);
+  return hipGetLastError();
+}
+hipError_t shk_fill_mimc_units(fp* wit, fp* inputs, uint64_t steps, uint32_t first_unit, uint32_t batch, uint32_t constant,
+                               hipStream_t st) {
+  if (!batch || !steps) return hipSuccess;
+  hipLaunchKernelGGL(fill_mimc_units_kernel, dim3((batch + 63) / 64), dim3(64), 0, st, wit, inputs, steps, first_unit, batch,
+                     constant);
   return hipGetLastError();
 }
 hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipStream_t st) {

@@ -1,6 +1,8 @@
 // ntt.hip -- instantiations and launchers of the NTT tile passes (ntt_kernels.cuh).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "ntt_kernels.cuh"
 
 namespace {
@@ -11,12 +13,17 @@ hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
   constexpr int THREADS = 1 << (TILE_LOG - 2);
   constexpr size_t LDS = (size_t)32 << TILE_LOG;
   auto k = ntt_pass_kernel<LOG_R, LOG_T, LAST>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LDS);
+  // the attribute is per device: one bit per device ordinal, per instantiation (contexts on several devices, and on
+  // several host threads, share this function)
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_done.fetch_or(bit, std::memory_order_release);
   }
   const uint64_t tiles = (a.total + ((1ull << LOG_T) - 1)) >> LOG_T;
   if (tiles == 0) return hipSuccess;

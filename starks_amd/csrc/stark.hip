@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(TPB) stark_trace_points_kernel(StarkArgs a) {
       uint32_t nz = 0;
 #pragma unroll
       for (int w = 0; w < 8; ++w) nz |= cz.v[w];
-      if (nz) atomicOr(a.bad, 1u);
+      if (nz) atomicOr(a.bad + b, 1u);
       // x C'(x) = Q_c(g1 x) - sum_v (d step_c / d X_v)(P(x)) Q_v(x)
       fp dsum = fp_zero();
 #pragma unroll 1

@@ -92,6 +92,10 @@ def unpack_proof(flat, steps, ext, width, degree, samples=SPOT_CHECKS):
 
 def prove_flat(witness_bytes, input_bytes, steps, ext, width, step_polys, batch=1, samples=SPOT_CHECKS):
     """witness_bytes: [batch][width][steps] wire form, input_bytes: [batch][width] -> batch flat proofs (concatenated)."""
+    if len(witness_bytes) != 32 * batch * width * steps or len(input_bytes) != 32 * batch * width:
+        raise ValueError("witness must hold batch*width*steps and inputs batch*width 32-byte elements "
+                         "(got %d and %d bytes for batch=%d, width=%d, steps=%d)"
+                         % (len(witness_bytes), len(input_bytes), batch, width, steps))
     coefs, exps, counts, degree = pack_step_polys(step_polys, width)
     plen = proof_len(steps, ext, width, degree, samples)
     if plen == 0:
@@ -133,6 +137,8 @@ class STARK(object):
         """stark.py:233-279.  witness[dim][step]; boundary[dim] = (step, dim, input value)."""
         if len(witness) != self.width or any(len(col) != self.steps for col in witness):
             raise ValueError("witness must be width x steps")
+        if len(boundary) < self.width:
+            raise IndexError("boundary must hold one (step, dim, value) constraint per dimension")  # boundary[dim], stark.py:91
         wb = b"".join(_lib.to_wire(col) for col in witness)
         ib = _lib.to_wire([constraint[2] for constraint in boundary[:self.width]])
         flat = prove_flat(wb, ib, self.steps, self.extension_factor, self.width, self.step_polys)

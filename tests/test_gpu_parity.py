@@ -843,3 +843,123 @@ def test_full_size_merkle_2_24_branches_verify(sa):
     finally:
         L.sh_dev_free(ctx, dx)
         L.sh_dev_free(ctx, dt)
+
+
+# ---- round 2: reference-independent pins for config 4, config 5 at its size, the new ABI entries -------------------------
+@pytest.mark.parametrize("logn", [22, 24])
+def test_ntt_large_digests_vs_oracle_fixture(sa, logn):
+    """Config 4 (2^24) and 2^22: forward and inverse transforms of the seeded vector against the digests the C oracle
+    produced (tests/golden/ntt_large.json; the oracle is pinned to the live reference up to 2^20)."""
+    import ctypes
+    c = [c for c in load_golden("ntt_large.json")["cases"] if c["logn"] == logn][0]
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << logn
+    w = root_of(n).to_bytes(32, "big")
+    assert w.hex() == c["w"]
+    dx, dy = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dx)) == 0 and L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dy)) == 0
+    assert L.sh_dev_fill_seeded(ctx, dx, n, c["seed"]) == 0
+    host = ctypes.create_string_buffer(32 * n)
+    for inverse, key, head in ((0, "sha_fwd", "fwd_head"), (1, "sha_inv", "inv_head")):
+        assert L.sh_dev_ntt(ctx, dx, dy, n, 1, w, inverse) == 0
+        assert L.sh_dev_to_wire(ctx, dy, host, n) == 0
+        assert host.raw[:64].hex() == c[head]
+        assert hashlib.sha256(host.raw).hexdigest() == c[key], (logn, key)
+    assert L.sh_dev_free(ctx, dx) == 0 and L.sh_dev_free(ctx, dy) == 0
+
+
+def test_config5_all_512_units_at_size(sa, oracle):
+    """BASELINE configs[4] at its size on one GPU: 512 independent 2^16-step MiMC STARK proofs in batched launches of 32
+    (device-generated witnesses).  A sample of units equals the same unit proved alone from a host-built witness, byte for
+    byte; one of them passes both verifiers; all 512 proofs are distinct."""
+    from starks_amd import batch, stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    steps, ext, total = 1 << 16, 8, 512
+    sample = {0, 31, 32, 257, 511}
+    digs, kept = batch.prove_stark_units_device(0, total, steps, ext, chunk=32, keep=sample)
+    assert len(digs) == total and len(set(digs)) == total and set(kept) == sample
+    for j in sorted(sample):
+        (jj, alone), = batch.prove_stark_batch([j], steps, ext, chunk=1)
+        assert jj == j and alone == kept[j], j
+        assert batch.digest(alone) == digs[j]
+    X1, X2 = generate_Xi_s(sa.F, 2)
+    S = stark.STARK(sa.F, steps, ext, 2, [X1, X1 + X2**3])
+    w, inp = batch.mimc_stark_unit(511, steps)
+    pr = stark.unpack_proof(kept[511], steps, ext, 2, 3)
+    assert S.verify_proof(pr, w, [(0, j, v) for j, v in enumerate(inp)])
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    assert oracle.py.verify_stark_proof(pr, [c[-1] for c in w], inp, sp, steps, ext)
+
+
+def test_mimc_unit_generator_status_batch_and_trim(sa, oracle):
+    """sh_dev_fill_mimc_units == batch.mimc_stark_unit; sh_stark_status_batch names the invalid proof of a batch;
+    sh_ctx_trim drops the caches and the next proof is rebuilt to the same bytes."""
+    import ctypes
+    from starks_amd import batch, stark
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    steps, ext, k = 64, 8, 3
+    pr = batch.StarkUnitProver(steps, ext, chunk=k)
+    pr.generate(7, k)
+    host = ctypes.create_string_buffer(64 * steps * k)
+    sa.lib.check(L.sh_dev_to_wire(ctx, pr.dw, host, 2 * steps * k), "dl")
+    want = b"".join(wire(col) for j in range(7, 7 + k) for col in batch.mimc_stark_unit(j, steps)[0])
+    assert host.raw == want
+    hin = ctypes.create_string_buffer(64 * k)
+    sa.lib.check(L.sh_dev_to_wire(ctx, pr.di, hin, 2 * k), "dl")
+    assert hin.raw == b"".join(wire(batch.mimc_stark_unit(j, steps)[1]) for j in range(7, 7 + k))
+    pr.prove(k)
+    good = pr.download(k)
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    for i, j in enumerate(range(7, 7 + k)):
+        w, inp = batch.mimc_stark_unit(j, steps)
+        assert good[i] == oracle.py.stark_flat(oracle.py.mk_stark_proof(w, inp, sp, steps, ext))
+    # break unit 1 of the batch only
+    pr.generate(7, k)
+    bad_elem = wire([5])
+    sa.lib.check(L.sh_dev_from_wire(ctx, bad_elem, ctypes.c_void_p(pr.dw.value + 32 * (1 * 2 * steps + steps + 9)), 1), "poke")
+    pr.prove(k)
+    flags = ctypes.create_string_buffer(k)
+    assert L.sh_stark_status_batch(ctx, flags, k) == -8
+    assert flags.raw == b"\x00\x01\x00"
+    assert L.sh_stark_status_batch(ctx, flags, k) == 0 and flags.raw == b"\x00" * k
+    # an unchecked failure of the device API does not leak into the next host-API call
+    pr.generate(7, k)
+    sa.lib.check(L.sh_dev_from_wire(ctx, bad_elem, ctypes.c_void_p(pr.dw.value + 32 * (steps + 9)), 1), "poke")
+    pr.prove(k)
+    w, inp = batch.mimc_stark_unit(8, steps)
+    X = pr.coefs, pr.exps, pr.counts
+    out = ctypes.create_string_buffer(pr.plen)
+    assert L.sh_stark_prove(ctx, b"".join(wire(c) for c in w), wire(inp), steps, ext, 2, X[0], X[1], X[2], 80, 1, out, pr.plen) == 0
+    assert out.raw == good[1]
+    # trim: everything cached is dropped and rebuilt
+    assert L.sh_ctx_trim(ctx) == 0
+    pr.generate(7, k)
+    pr.prove(k)
+    assert pr.download(k) == good
+    pr.close()
+
+
+@pytest.mark.parametrize("args", [["--workload", "c5", "--quick"],
+                                  ["--quick", "--steps", "2", "--warmup", "1", "--no-extras", "--logn", "14"]])
+def test_bench_two_ranks_share_this_gpu(sa, args):
+    """bench.py --gpus 2 starts its own two ranks (gloo control plane, both on this box's GPU): the N > 1 path of both
+    workloads with real GPU work -- sharding by proof index, header all_gather, max-over-ranks timing, one JSON line."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--no-cpu-baseline"] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    c5 = line["c5"]
+    assert c5["n_gpus"] == 2 and c5["units_per_rank"] == [8, 8] and c5["check"]["ok"] is True
+    assert c5["check"]["rank0"]["batch_equals_single"] is True and c5["check"]["rank0"]["verifies"] is True
+    if line["metric"] == "ntt_field_elements_per_sec":
+        assert line["check"]["roundtrip_ok"] is True and line["scaling"] == "weak"
+    else:
+        assert line["scaling"] == "strong" and line["unit"] == "proofs/s"

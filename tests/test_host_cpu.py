@@ -163,6 +163,26 @@ def test_stark_host_mirror_on_reference_proofs():
             S.verify_proof(bad, witness, boundary)
 
 
+def test_prover_input_shape_errors():
+    """Short witness / input buffers and short boundary lists are refused on the host (the C side would read past them)."""
+    from starks_amd import IntegersModP, stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    F = IntegersModP(P)
+    X1, X2 = generate_Xi_s(F, 2)
+    polys = [X1, X1 + X2**3]
+    with pytest.raises(ValueError):
+        stark.prove_flat(bytes(32 * 2 * 8 - 32), bytes(64), 8, 8, 2, polys)
+    with pytest.raises(ValueError):
+        stark.prove_flat(bytes(32 * 2 * 8), bytes(32), 8, 8, 2, polys)
+    with pytest.raises(ValueError):
+        stark.prove_flat(bytes(32 * 2 * 8), bytes(64), 8, 8, 2, polys, batch=2)
+    S = stark.STARK(F, 8, 8, 2, polys)
+    with pytest.raises(IndexError):   # the reference fails at boundary[dim] (stark.py:91)
+        S.mk_proof([[1] * 8, [2] * 8], [(0, 0, 1)])
+    with pytest.raises(ValueError):
+        S.mk_proof([[1] * 8], [(0, 0, 1), (0, 1, 2)])
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """include/starkhip.h is C99 and a plain C program can link the library and call its host-only entry points."""
     import subprocess
@@ -179,6 +199,8 @@ int main(void) {
   if (sh_stark_proof_len(8, 8, 2, 3, 80) != 147808) return 4;   /* tests/golden/stark.json: mimc_w2_s8 */
   if (sh_stark_proof_len(8, 8, 10, 3, 80) != 0) return 5;
   if (sh_ntt(NULL, NULL, 0, NULL, 8, NULL, 0) != SH_ERR_INVALID) return 6;
+  if (sh_ntt_passes(1u << 20) != 3 || sh_ntt_passes(256) != 1 || sh_ntt_passes(6) != 0) return 7;
+  if (sh_ctx_trim(NULL) != SH_ERR_INVALID || sh_stark_status_batch(NULL, NULL, 0) != SH_ERR_INVALID) return 8;
   printf("ok\n");
   return 0;
 }

@@ -53,3 +53,42 @@ def test_two_rank_gloo_gather(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     want = hashlib.sha256(b"".join(hashlib.sha256(b"proof-%d" % j).digest() for j in range(11))).hexdigest()
     assert "GATHER_OK 2 11 " + want in out.stdout
+
+
+def _bench(args, timeout=300):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]   # ONE JSON line, printed by rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts 2 ranks itself (gloo rendezvous on 127.0.0.1), shards the
+    units and gathers the fixed-size headers; --dry-run replaces the GPU work, so `value` is null and labelled."""
+    line = _bench(["--gpus", "2", "--workload", "c5", "--units", "11", "--dry-run"])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None
+    assert line["units_per_rank"] == [6, 5] and line["gather_ok"] is True
+    one = _bench(["--gpus", "1", "--dry-run", "--units", "5"])
+    assert one["n_gpus"] == 1 and one["units_per_rank"] == [5]
+
+
+def test_bench_refuses_to_run_without_gpu():
+    """No CPU fallback in the bench either: without --dry-run and without a GPU it fails loudly."""
+    import __graft_entry__ as ge
+    ge.build()
+    from starks_amd import _lib
+    if _lib.lib().sh_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is present")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick", "--no-cpu-baseline"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "{" not in out.stdout
