@@ -1,6 +1,7 @@
 // capi.hip -- host side of libstarkhip.so: context, twiddle-table plans, the NTT / LDE / Merkle / FRI
 // drivers and the C ABI declared in include/starkhip.h.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -10,6 +11,7 @@
 
 #include "../../include/starkhip.h"
 #include "internal.hpp"
+#include "mfma_tw.cuh"
 
 namespace {
 
@@ -78,6 +80,8 @@ struct NttPlan {
   fp root;                   // effective root (already inverted for inverse transforms)
   std::vector<int> radix;    // log2 radix of each pass
   std::vector<fp*> wR;       // per pass: powers of root^(n/R), R/2 entries
+  std::vector<fp*> tw2;      // per column pass: [k][j2] copy of tw for the MFMA tile pass (null when it is not used)
+  std::vector<void*> mats;   // per pass: the same powers as MFMA operand images (TwMat[R/2]), null for radix < 2^5
   std::vector<PowTable> tw;  // per column pass d: table of root^(P_d) (times n^-1 on pass 0 when scaled)
   PowTable base;             // unscaled table of root (sh_power_cycle, FRI fold)
   fp* scale = nullptr;       // n^-1 on the device (one-pass scaled plans)
@@ -231,25 +235,63 @@ int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) 
   return SH_OK;
 }
 
-// table of factor * g^e, e < 2^log_order (factor may be null)
-int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp* factor, PowTable* out) {
-  const bool direct = log_order <= DIRECT_TABLE_LOG;
-  const int lb = direct ? log_order : (log_order + 1) / 2;
+// STARKHIP_NTT_PATH=valu keeps every pass on the integer-VALU kernels (ntt_kernels.cuh), for A/B measurements
+bool use_mfma_path() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_NTT_PATH");
+    v = (e && !strcmp(e, "valu")) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+// table of factor * g^e, e < 2^log_order (factor may be null).  Up to 2^direct_log entries the table is stored in full
+// (one load per lookup); larger ones as two halves lo[e & mask] * hi[e >> lb] (one more modmul per lookup).  Full tables
+// above 2^18 entries are expanded on the device from the two halves.
+int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp* factor, PowTable* out,
+                    int direct_log = DIRECT_TABLE_LOG) {
+  const bool direct = log_order <= direct_log;
+  const bool host_direct = direct && log_order <= DIRECT_TABLE_LOG;
+  const int lb = host_direct ? log_order : (log_order + 1) / 2;
   std::vector<fp> lo((size_t)1 << lb);
   lo[0] = fp_one();
   for (size_t i = 1; i < lo.size(); ++i) lo[i] = fp_mul(lo[i - 1], g);
   const fp gs = fp_mul(lo.back(), g);  // g^(2^lb)
-  if (direct && factor)
+  if (host_direct && factor)
     for (auto& v : lo) v = fp_mul(v, *factor);
-  SH_TRY(upload_table(c, pl, lo, &out->lo));
-  out->lb = (uint32_t)lb;
-  out->hi = nullptr;
-  if (!direct) {
-    std::vector<fp> hi((size_t)1 << (log_order - lb));
-    hi[0] = factor ? *factor : fp_one();
-    for (size_t i = 1; i < hi.size(); ++i) hi[i] = fp_mul(hi[i - 1], gs);
-    SH_TRY(upload_table(c, pl, hi, &out->hi));
+  if (host_direct) {
+    SH_TRY(upload_table(c, pl, lo, &out->lo));
+    out->lb = (uint32_t)lb;
+    out->hi = nullptr;
+    return SH_OK;
   }
+  std::vector<fp> hi((size_t)1 << (log_order - lb));
+  hi[0] = factor ? *factor : fp_one();
+  for (size_t i = 1; i < hi.size(); ++i) hi[i] = fp_mul(hi[i - 1], gs);
+  if (!direct) {
+    SH_TRY(upload_table(c, pl, lo, &out->lo));
+    SH_TRY(upload_table(c, pl, hi, &out->hi));
+    out->lb = (uint32_t)lb;
+    return SH_OK;
+  }
+  // expand on the device: full[e] = lo[e & mask] * hi[e >> lb]
+  void *dlo = nullptr, *dhi = nullptr, *full = nullptr;
+  HIP_TRY(c, hipMalloc(&full, sizeof(fp) << log_order));
+  pl->owned.push_back(full);
+  hipError_t e = hipMalloc(&dlo, lo.size() * sizeof(fp));
+  if (e == hipSuccess) e = hipMalloc(&dhi, hi.size() * sizeof(fp));
+  if (e == hipSuccess) e = hipMemcpy(dlo, lo.data(), lo.size() * sizeof(fp), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dhi, hi.data(), hi.size() * sizeof(fp), hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = shk_powers(reinterpret_cast<fp*>(dlo), reinterpret_cast<fp*>(dhi), (uint32_t)lb, reinterpret_cast<fp*>(full),
+                   (uint64_t)1 << log_order, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (dlo) (void)hipFree(dlo);
+  if (dhi) (void)hipFree(dhi);
+  HIP_TRY(c, e);
+  out->lo = reinterpret_cast<fp*>(full);
+  out->hi = nullptr;
+  out->lb = (uint32_t)log_order;
   return SH_OK;
 }
 
@@ -331,6 +373,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
   int rc = build_pow_table(c, pl, root_eff, pl->log_n, nullptr, &pl->base);
   if (rc == SH_OK && pl->log_n >= 2) {
     std::map<int, fp*> wr_by_radix;
+    std::map<int, void*> mats_by_radix;
     int log_P = 0;
     for (size_t d = 0; d < m && rc == SH_OK; ++d) {
       const int r = pl->radix[d];
@@ -342,8 +385,22 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
         fp* dev = nullptr;
         rc = upload_table(c, pl, t, &dev);
         wr_by_radix[r] = dev;
+        mats_by_radix[r] = nullptr;
+        if (rc == SH_OK && r >= 5 && r <= 8) {  // operand images for the matrix-core butterflies (ntt_mfma.hip)
+          std::vector<TwMat> mm(t.size());
+          for (size_t i = 0; i < t.size(); ++i)
+            if (!shk_build_twmat(t[i], &mm[i])) rc = SH_ERR_INVALID;
+          void* d = nullptr;
+          if (rc == SH_OK) {
+            HIP_TRY(c, hipMalloc(&d, mm.size() * sizeof(TwMat)));
+            pl->owned.push_back(d);
+            HIP_TRY(c, hipMemcpy(d, mm.data(), mm.size() * sizeof(TwMat), hipMemcpyHostToDevice));
+          }
+          mats_by_radix[r] = d;
+        }
       }
       pl->wR.push_back(wr_by_radix[r]);
+      pl->mats.push_back(mats_by_radix[r]);
       if (rc == SH_OK && d + 1 < m) {
         PowTable t;
         if (d == 0 && !scaled) {
@@ -353,6 +410,18 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
           rc = build_pow_table(c, pl, g, pl->log_n - log_P, (d == 0 && scaled) ? &ninv : nullptr, &t);
         }
         pl->tw.push_back(t);
+        // the MFMA tile pass reads its inter-pass twiddles as rows of 32 adjacent columns: [k][j2] copy of the table
+        fp* tw2 = nullptr;
+        const int log_S = pl->log_n - log_P - r;
+        if (rc == SH_OK && use_mfma_path() && r >= 5 && r <= 8 && log_S >= 5) {
+          void* dv = nullptr;
+          HIP_TRY(c, hipMalloc(&dv, sizeof(fp) << (r + log_S)));
+          pl->owned.push_back(dv);
+          tw2 = reinterpret_cast<fp*>(dv);
+          HIP_TRY(c, shk_tw2(t.lo, t.hi, t.lb, tw2, (uint32_t)r, (uint32_t)log_S, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        pl->tw2.push_back(tw2);
       }
       log_P += r;
     }
@@ -404,6 +473,7 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch) {
       a.tw_hi = pl->tw[d].hi;
       a.tw_lb = pl->tw[d].lb;
       a.tw_direct = pl->tw[d].hi == nullptr;
+      a.tw2 = pl->tw2[d];
       src = work;
     } else {
       a.src = src;
@@ -414,7 +484,17 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch) {
       for (size_t k = 0; k + 1 < m; ++k) a.dig_log[k] = (uint32_t)pl->radix[k];
       a.scale = (m == 1) ? pl->scale : nullptr;
     }
-    HIP_TRY(c, shk_launch_ntt_pass(r, last, a, c->stream));
+    a.mats = use_mfma_path() ? pl->mats[d] : nullptr;
+#ifdef SHK_STAMPS
+    {
+      const char* e = getenv("STARKHIP_STAMP_PASS");
+      a.debug = (size_t)(e ? atoi(e) : (int)m - 1) == d;
+    }
+#endif
+    if (shk_ntt_mfma_supports(r, last, a))
+      HIP_TRY(c, shk_launch_ntt_pass_mfma(r, last, a, c->stream));
+    else
+      HIP_TRY(c, shk_launch_ntt_pass(r, last, a, c->stream));
     log_P += r;
   }
   return SH_OK;

@@ -22,12 +22,19 @@ struct NttPassArgs {
   uint32_t ndig;
   uint32_t dig_log[3];
   const fp* scale;    // row pass: optional factor applied to every output (n^-1 of a one-pass inverse)
+  uint32_t debug;     // diagnostic (SHK_STAMPS) builds only: 1 = this pass records its phase stamps
+  const fp* tw2;      // MFMA column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k); else null
+  const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null
 };
 
 // ---- ntt.hip ----------------------------------------------------------------------------------
 // Launch one tile pass (radix 2^log_R).  Returns hipSuccess or the launch error.
 hipError_t shk_launch_ntt_pass(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
 hipError_t shk_launch_ntt_tiny(const fp* src, fp* dst, uint32_t n, uint32_t batch, const fp* scale, hipStream_t st);
+// ntt_mfma.hip: the same pass with the tile in registers (R rows x 32 columns) and the butterfly products on the matrix
+// cores; supports radix 2^5 .. 2^8, column passes with S >= 32 and every row pass
+bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a);
+hipError_t shk_launch_ntt_pass_mfma(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
 constexpr int SHK_TILE_LOG = 10;  // default tile: 1024 elements (32 KiB of LDS, 256 threads) per workgroup -> 5 workgroups per CU
 
 // ---- kernels.hip: conversions, powers, Merkle, FRI fold, sampling, branch gather ------------------
@@ -39,6 +46,7 @@ hipError_t shk_fill_mimc_units(fp* wit, fp* inputs, uint64_t steps, uint32_t fir
 hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipStream_t st);
 // out[i] = g^i for i < n, g given by its two-level table (lo, hi, lb)
 hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st);
+hipError_t shk_tw2(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint32_t log_R, uint32_t log_S, hipStream_t st);
 // zero-pad: dst[b][0..n_in) = src[b][0..n_in), dst[b][n_in..n) = 0
 hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st);
 // Merkle tree of `batch` arrays of n limb-form values (or n raw 32-byte leaves when raw_leaves).

@@ -85,6 +85,17 @@ __global__ void __launch_bounds__(TPB) powers_kernel(const fp* lo, const fp* hi,
   if (hi) v = fp_mul(v, fp_load(hi + (i >> lb)));
   fp_store(out + i, v);
 }
+// inter-pass twiddles of one column pass laid out the way the MFMA tile pass reads them: out[k * S + j2] = g^(j2 * k)
+// (g of order R * S given by its power table), so that the 32 adjacent columns of a tile read 1 KiB contiguous per row
+__global__ void __launch_bounds__(TPB) tw2_kernel(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint32_t log_R, uint32_t log_S) {
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >> (log_R + log_S)) return;
+  const uint64_t k = g >> log_S, j2 = g & ((1ull << log_S) - 1);
+  const uint64_t e = (j2 * k) & ((1ull << (log_R + log_S)) - 1);
+  fp v = fp_load(lo + (hi ? (e & ((1ull << lb) - 1)) : e));
+  if (hi) v = fp_mul(v, fp_load(hi + (e >> lb)));
+  fp_store(out + g, v);
+}
 __global__ void __launch_bounds__(TPB) pad_copy_kernel(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint64_t total) {
   uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   if (g >= total) return;
@@ -445,6 +456,11 @@ hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipS
 hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, lo, hi, lb, out, n);
+  return hipGetLastError();
+}
+hipError_t shk_tw2(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint32_t log_R, uint32_t log_S, hipStream_t st) {
+  const uint64_t n = 1ull << (log_R + log_S);
+  hipLaunchKernelGGL(tw2_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, lo, hi, lb, out, log_R, log_S);
   return hipGetLastError();
 }
 hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st) {

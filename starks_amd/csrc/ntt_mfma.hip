@@ -1,0 +1,325 @@
+// ntt_mfma.hip -- radix-2^r passes of the large NTT with the butterflies' twiddle products on the matrix cores.
+// Same decomposition, same tables of values and same results as ntt_kernels.cuh (the reference's _fft/_simple_ft,
+// starks/fft.py:287-314, natural order in and out); what changes is where a pass keeps its data and how it multiplies.
+//
+// A workgroup owns a tile of R rows x 32 COLUMNS and keeps it in registers: 2R threads, 16 elements each.  Lane l of a
+// wave is column l & 31; the row index never reaches the low five lane bits.  Every butterfly twiddle of a tile
+// transform depends on the row only, so the 32 lanes of a half-wave always share it and the product (a - b) * w runs as
+// one byte-matrix x byte-vector MFMA for all of them (mfma_tw.cuh).  Only the inter-pass twiddle g^(j2 * k), which
+// differs per column, is a general 256-bit modmul on the VALUs (fp_mul).
+//   stage 1: rows i = m * (R/16) + rho, m = 0..15 in registers (rho = the thread's row group): the four top DIF levels
+//            without any exchange; the two half-waves of a wave are different row groups (two twiddle matrices per MFMA
+//            pair);
+//   exchange through LDS (64 KiB at a time: a column half / quarter per round, so that every thread writes and reads all
+//            of its 16 elements in the same round and needs no second register set);
+//   stage 2: rows i = 16 * mu + m', m' = 0..15 in registers: the remaining r - 4 levels, whose twiddles are the same for
+//            every thread (one matrix, compile-time index; twiddle 1 is a plain subtraction);
+//   DIF leaves position i holding frequency bitrev(i); the store addresses undo that.
+// Column pass (LAST = false): the 32 columns are adjacent (1 KiB contiguous per row), loads and stores are direct.
+// Row pass (LAST = true): a "column" is one contiguous row of R points; rows are staged through LDS (lanes along the row
+// for the global load), and the result is scattered to natural order with 32 adjacent outputs per frequency.
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+#include <utility>
+
+#include "internal.hpp"
+#include "mfma_tw.cuh"
+#include "ntt_kernels.cuh"
+
+#ifdef SHK_STAMPS
+// diagnostic build only (make STAMPS=1 -> libstarkhip_stamps.so): s_memtime at the phase boundaries of wave 0 of the
+// first 1024 workgroups of the most recent tile pass; never compiled into the product library
+__device__ unsigned long long g_stamps[8][1024];
+#define STAMP(k)                                                                                     \
+  do {                                                                                               \
+    if (a.debug && threadIdx.x == 0 && blockIdx.x < 1024) g_stamps[k][blockIdx.x] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+extern "C" int sh_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) == hipSuccess ? 0 : -3;
+}
+#else
+#define STAMP(k)
+#endif
+
+namespace {
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  The butterfly bodies contain
+// convergent operations (MFMA operands moved with v_permlane32_swap, ballots), which `#pragma unroll` refuses to unroll;
+// the 16 elements of a thread must be addressed with constant indices to stay in registers.
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// LDS window of one exchange round: RW rows x CW columns of 32-byte elements, the column slot XOR-ed with the row so
+// that both access patterns (lanes along the columns of one row, lanes along the rows of one column) spread over banks.
+template <int LOG_CW>
+__device__ __forceinline__ uint32_t win_slot(uint32_t i, uint32_t c) {
+  constexpr uint32_t CW = 1u << LOG_CW;
+  return ((i << LOG_CW) | ((c ^ i) & (CW - 1u))) * 2u;  // in uint4 units
+}
+
+template <int LOG_R>
+__device__ __forceinline__ void row_coords(const NttPassArgs& a, uint64_t col, uint64_t* gbase, uint64_t* obase) {
+  // the row pass of ntt_kernels.cuh: tiles enumerate rows with the FIRST pass's digit fastest, so that 32 rows of a
+  // tile land on 32 adjacent output addresses
+  const uint64_t b = col >> a.log_P;
+  const uint32_t pp = (uint32_t)(col & ((1ull << a.log_P) - 1));
+  const uint32_t lr1 = a.ndig ? a.dig_log[0] : 0;
+  const uint32_t k1 = pp & ((1u << lr1) - 1u);
+  const uint32_t rst = pp >> lr1;
+  const uint32_t p = (k1 << (a.log_P - lr1)) | rst;
+  uint32_t sh = a.log_P, wl = 0, acc = 0;
+#pragma unroll
+  for (uint32_t d = 0; d < 3; ++d) {
+    if (d < a.ndig) {
+      sh -= a.dig_log[d];
+      acc |= ((p >> sh) & ((1u << a.dig_log[d]) - 1u)) << wl;
+      wl += a.dig_log[d];
+    }
+  }
+  *gbase = (b << a.log_n) + ((uint64_t)p << LOG_R);
+  *obase = (b << a.log_n) + acc;
+}
+
+template <int LOG_R, bool LAST>
+__global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu(2, 2))) ntt_ctile_kernel(NttPassArgs a) {
+  static_assert(LOG_R >= 5 && LOG_R <= 8, "unsupported radix");
+  constexpr int R = 1 << LOG_R;
+  constexpr int G = R / 16;                       // row groups = 2 per wave
+  constexpr int THREADS = 2 * R;
+  // LDS window of an exchange round: all R rows of 16 columns (R/2 KiB), two rounds.  Sized so that two waves per SIMD
+  // fit whatever the radix: 8 / 4 / 2 / 1 workgroups per CU for R = 32 / 64 / 128 / 256 use 16 / 32 / 64 / 128 KiB each.
+  constexpr int NR = 2;
+  constexpr int LOG_CW = 4;
+  constexpr int CW = 1 << LOG_CW;
+  constexpr int QMAX = LOG_R - 5 < 3 ? LOG_R - 5 : 3;   // top level of stage 2
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t c = lane & 31u, hb = lane >> 5;
+  const uint32_t rho = 2u * wave + hb;  // row group of stage 1, and row block mu of stage 2
+  const uint64_t col = ((uint64_t)blockIdx.x << 5) + c;
+  const bool active = col < a.total;
+  const shk_v16i cinit = shk_mfma_cinit(lane);
+  const TwMat* mats = reinterpret_cast<const TwMat*>(a.mats);
+
+  uint64_t gbase = 0, obase = 0, j2 = 0;
+  if (LAST) {
+    row_coords<LOG_R>(a, col, &gbase, &obase);
+  } else {
+    j2 = col & ((1ull << a.log_S) - 1);
+    gbase = ((col >> a.log_S) << (LOG_R + a.log_S)) + j2;
+  }
+
+  fp x[16];
+  STAMP(0);
+  // ---- load ------------------------------------------------------------------------------------------------------
+  if (!LAST) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const uint32_t i = (uint32_t)m * G + rho;
+      x[m] = active ? fp_load(a.src + gbase + ((uint64_t)i << a.log_S)) : fp_zero();
+    }
+  } else {
+    // rows are contiguous: lanes run along the row for the global load, the tile is transposed through LDS, CW rows
+    // (= tile columns) per round
+    constexpr int LOG_SEG = LOG_R < 6 ? LOG_R : 6;   // points of a row covered by one sweep of lanes
+    constexpr int SEG = 1 << LOG_SEG;
+    constexpr int ROWS_PER_SWEEP = THREADS / SEG;
+    constexpr int ELEMS = CW * R / THREADS;           // per thread per round
+    constexpr int SWEEPS_PER_ROW = R / SEG;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      if (k > 0) __syncthreads();
+#pragma unroll
+      for (int e = 0; e < ELEMS; ++e) {
+        // sweep e covers rows [e / SWEEPS_PER_ROW ...]: thread -> (row r_l inside the round, point i)
+        const uint32_t flat = (uint32_t)e * THREADS + tid;           // < CW * R
+        const uint32_t r_l = flat >> LOG_R, i = flat & (R - 1);
+        const uint64_t rcol = ((uint64_t)blockIdx.x << 5) + (uint32_t)k * CW + r_l;
+        fp v = fp_zero();
+        if (rcol < a.total) {
+          uint64_t gb, ob;
+          row_coords<LOG_R>(a, rcol, &gb, &ob);
+          v = fp_load(a.src + gb + i);
+        }
+        lds_put_at(lds, win_slot<LOG_CW>(i, r_l), v);
+      }
+      __syncthreads();
+      if ((c >> LOG_CW) == (uint32_t)k) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = lds_get_at(lds, win_slot<LOG_CW>((uint32_t)m * G + rho, c & (CW - 1)));
+      }
+    }
+    (void)ROWS_PER_SWEEP;
+    (void)SWEEPS_PER_ROW;
+    __syncthreads();
+  }
+
+  // ---- stage 1: levels q = LOG_R-1 .. LOG_R-4 on the register index m (bit mu = 3 .. 0) -----------------------------
+  STAMP(1);
+  {
+    // the fragments of butterfly j + 1 are requested before butterfly j is computed (L2 latency behind ~130 VALU
+    // instructions); consecutive butterflies with the same twiddle keep their fragments
+    const uint32_t rho_lo = 2u * wave, rho_hi = rho_lo + 1u;
+    struct Frag4 {
+      shk_v4i w1, n1, w2, n2;
+    };
+    auto frags_of = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int mu = 3 - j / 8, b = j % 8;
+      constexpr int m0 = ((b >> mu) << (mu + 1)) | (b & ((1 << mu) - 1));
+      constexpr uint32_t eb = (uint32_t)(m0 & ((1 << mu) - 1)) * G;
+      const TwMat* t1 = mats + ((eb + rho_lo) << (3 - mu));
+      const TwMat* t2 = mats + ((eb + rho_hi) << (3 - mu));
+      Frag4 f;
+      f.w1 = shk_ld_frag(t1->w, lane);
+      f.n1 = shk_ld_frag(t1->nw, lane);
+      f.w2 = shk_ld_frag(t2->w, lane);
+      f.n2 = shk_ld_frag(t2->nw, lane);
+      return f;
+    };
+    Frag4 cur = frags_of(std::integral_constant<int, 0>{});
+    static_for<32>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int mu = 3 - j / 8, b = j % 8;
+      constexpr int m0 = ((b >> mu) << (mu + 1)) | (b & ((1 << mu) - 1));
+      constexpr int m1 = m0 | (1 << mu);
+      Frag4 nxt = cur;
+      if constexpr (j + 1 < 32) {
+        constexpr int mu2 = 3 - (j + 1) / 8, b2 = (j + 1) % 8;
+        constexpr int m02 = ((b2 >> mu2) << (mu2 + 1)) | (b2 & ((1 << mu2) - 1));
+        constexpr bool same = mu2 == mu && (m02 & ((1 << mu2) - 1)) == (m0 & ((1 << mu) - 1));
+        if constexpr (!same) nxt = frags_of(std::integral_constant<int, j + 1>{});
+      }
+      const fp d = shk_mfma_submul2(x[m0], x[m1], cur.w1, cur.n1, cur.w2, cur.n2, cinit);
+      x[m0] = fp_add(x[m0], x[m1]);
+      x[m1] = d;
+      cur = nxt;
+    });
+  }
+
+  STAMP(2);
+  // ---- exchange: (m, rho) -> (mu', m') ---------------------------------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const bool mine = (c >> LOG_CW) == (uint32_t)k;
+    if (k > 0) __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) lds_put_at(lds, win_slot<LOG_CW>((uint32_t)m * G + rho, c & (CW - 1)), x[m]);
+    }
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = lds_get_at(lds, win_slot<LOG_CW>(16u * rho + (uint32_t)m, c & (CW - 1)));
+    }
+  }
+
+  STAMP(3);
+  // ---- stage 2: levels q = QMAX .. 0 on the register index m' (twiddles identical for every thread) ------------------
+  static_for<QMAX + 1>([&](auto lv) {
+    constexpr int q = QMAX - decltype(lv)::value;
+    static_for<8>([&](auto bi) {
+      constexpr int b = decltype(bi)::value;
+      constexpr int m0 = ((b >> q) << (q + 1)) | (b & ((1 << q) - 1));
+      constexpr int m1 = m0 | (1 << q);
+      constexpr int e = (m0 & ((1 << q) - 1)) << (LOG_R - 1 - q);
+      if constexpr (e == 0) {
+        const fp s = fp_add(x[m0], x[m1]);
+        x[m1] = fp_sub(x[m0], x[m1]);
+        x[m0] = s;
+      } else {
+        const TwMat* t = mats + e;
+        const shk_v4i w = shk_ld_frag(t->w, lane), nw = shk_ld_frag(t->nw, lane);
+        const fp d = shk_mfma_submul(x[m0], x[m1], w, nw, cinit);
+        x[m0] = fp_add(x[m0], x[m1]);
+        x[m1] = d;
+      }
+    });
+  });
+
+  // ---- store: position i = 16 rho + m' holds frequency k = bitrev(i) -----------------------------------------------------
+  STAMP(4);
+  if (!active) return;
+  if (LAST) {
+    static_for<16>([&](auto mi) {
+      constexpr int m = decltype(mi)::value;
+      const uint32_t i = 16u * rho + (uint32_t)m;
+      const uint32_t k = __brev(i) >> (32 - LOG_R);
+      fp v = x[m];
+      if (a.scale) v = fp_mul(v, fp_load(a.scale));
+      fp_store(a.dst + obase + ((uint64_t)k << a.log_P), v);
+    });
+  } else {
+    // inter-pass twiddles g^(j2 k) from the [k][j2] table (a tile's 32 columns read 1 KiB contiguous per row); eight are
+    // requested at a time so that their latency overlaps the modmuls of the previous ones
+    static_for<2>([&](auto gi) {
+      constexpr int g8 = decltype(gi)::value * 8;
+      fp tw[8];
+      static_for<8>([&](auto ti) {
+        constexpr int m = g8 + decltype(ti)::value;
+        const uint32_t k = __brev(16u * rho + (uint32_t)m) >> (32 - LOG_R);
+        tw[m - g8] = fp_load(a.tw2 + ((uint64_t)k << a.log_S) + j2);
+      });
+      static_for<8>([&](auto ti) {
+        constexpr int m = g8 + decltype(ti)::value;
+        const uint32_t k = __brev(16u * rho + (uint32_t)m) >> (32 - LOG_R);
+        fp_store(a.dst + gbase + ((uint64_t)k << a.log_S), fp_mul(x[m], tw[m - g8]));
+      });
+    });
+  }
+  STAMP(5);
+}
+
+template <int LOG_R, bool LAST>
+hipError_t launch_ctile(const NttPassArgs& a, hipStream_t st) {
+  constexpr int R = 1 << LOG_R;
+  constexpr size_t LDS = (size_t)R * 16 * 32;  // one exchange window: R rows x 16 columns
+  auto k = ntt_ctile_kernel<LOG_R, LAST>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return e;
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  const uint64_t tiles = (a.total + 31) >> 5;
+  if (tiles == 0) return hipSuccess;
+  if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(2 * R), LDS, st, a);
+  return hipGetLastError();
+}
+
+template <bool LAST>
+hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
+  switch (log_R) {
+    case 5: return launch_ctile<5, LAST>(a, st);
+    case 6: return launch_ctile<6, LAST>(a, st);
+    case 7: return launch_ctile<7, LAST>(a, st);
+    case 8: return launch_ctile<8, LAST>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a) {
+  if (log_R < 5 || log_R > 8 || !a.mats) return false;
+  if (!last && (a.log_S < 5 || !a.tw2)) return false;  // a tile's 32 columns must be adjacent
+  return true;
+}
+
+hipError_t shk_launch_ntt_pass_mfma(int log_R, bool last, const NttPassArgs& a, hipStream_t st) {
+  return last ? dispatch<true>(log_R, a, st) : dispatch<false>(log_R, a, st);
+}
