@@ -235,14 +235,27 @@ int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) 
   return SH_OK;
 }
 
-// STARKHIP_NTT_PATH=valu keeps every pass on the integer-VALU kernels (ntt_kernels.cuh), for A/B measurements
+// Which kernels run the tile passes.  Default: the integer-VALU passes (ntt_kernels.cuh).  STARKHIP_NTT_PATH=mfma selects
+// the matrix-core passes (ntt_mfma.hip) wherever they apply: measured within +-8 % of the VALU passes on every shape
+// (DESIGN.md section 5), ahead on large batches, behind on single vectors -- kept selectable, not default.
 bool use_mfma_path() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_NTT_PATH");
-    v = (e && !strcmp(e, "valu")) ? 0 : 1;
+    v = (e && !strcmp(e, "mfma")) ? 1 : 0;
   }
   return v == 1;
+}
+
+int tw2_max_log() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_TW2_MAX_LOG");
+    v = e ? atoi(e) : 22;  // measured: +5..9 % up to 2^20-entry tables; a 2^24-entry (512 MiB) table gains nothing
+    if (v < 0) v = 0;
+    if (v > 28) v = 28;
+  }
+  return v;
 }
 
 // table of factor * g^e, e < 2^log_order (factor may be null).  Up to 2^direct_log entries the table is stored in full
@@ -410,10 +423,13 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
           rc = build_pow_table(c, pl, g, pl->log_n - log_P, (d == 0 && scaled) ? &ninv : nullptr, &t);
         }
         pl->tw.push_back(t);
-        // the MFMA tile pass reads its inter-pass twiddles as rows of 32 adjacent columns: [k][j2] copy of the table
+        // the tile passes read their inter-pass twiddles g^(j2 k) as rows of adjacent columns: a [k][j2] copy of the
+        // table, tw2[k * S + j2] -- one coalesced load per element instead of a scattered one (plus, above 2^18
+        // entries, the second modmul of the two-half lookup).  n / P entries: 32 MiB for the first pass of 2^20 points;
+        // above 2^22 entries (STARKHIP_TW2_MAX_LOG) the pass keeps the power-table lookup.
         fp* tw2 = nullptr;
         const int log_S = pl->log_n - log_P - r;
-        if (rc == SH_OK && use_mfma_path() && r >= 5 && r <= 8 && log_S >= 5) {
+        if (rc == SH_OK && r + log_S <= tw2_max_log()) {
           void* dv = nullptr;
           HIP_TRY(c, hipMalloc(&dv, sizeof(fp) << (r + log_S)));
           pl->owned.push_back(dv);

@@ -43,6 +43,33 @@ __device__ __forceinline__ uint64_t shk_mad64(uint32_t a, uint32_t k, uint64_t c
   asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
   return d;
 }
+// 16 non-negative partial sums (< 2^22) at byte spacing -> 4 limbs + carry (< 2^15), for the two accumulators of a
+// butterfly at once: the two carry chains are independent, so their dependent v_mad_u64_u32 alternate (`asm volatile`
+// keeps the order) and neither waits on its own previous result
+__device__ __forceinline__ uint64_t shk_mad64v(uint32_t a, uint32_t k, uint64_t c) {
+  uint64_t d;
+  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
+  return d;
+}
+__device__ __forceinline__ void shk_norm16x2(const shk_v16i& s1, const shk_v16i& s2, uint32_t o1[5], uint32_t o2[5]) {
+  uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const uint32_t e1 = (uint32_t)s1[4 * m] + c1, e2 = (uint32_t)s2[4 * m] + c2;
+    uint64_t t1 = shk_mad64v((uint32_t)s1[4 * m + 1], 1u << 8, (uint64_t)e1);
+    uint64_t t2 = shk_mad64v((uint32_t)s2[4 * m + 1], 1u << 8, (uint64_t)e2);
+    t1 = shk_mad64v((uint32_t)s1[4 * m + 2], 1u << 16, t1);
+    t2 = shk_mad64v((uint32_t)s2[4 * m + 2], 1u << 16, t2);
+    t1 = shk_mad64v((uint32_t)s1[4 * m + 3], 1u << 24, t1);
+    t2 = shk_mad64v((uint32_t)s2[4 * m + 3], 1u << 24, t2);
+    o1[m] = (uint32_t)t1;
+    o2[m] = (uint32_t)t2;
+    c1 = (uint32_t)(t1 >> 32);
+    c2 = (uint32_t)(t2 >> 32);
+  }
+  o1[4] = c1;
+  o2[4] = c2;
+}
 // 16 non-negative partial sums (< 2^22) at byte spacing -> 4 limbs + carry (< 2^15)
 __device__ __forceinline__ void shk_norm16(const shk_v16i& s, uint32_t out[5]) {
   uint32_t cin = 0;
@@ -97,8 +124,7 @@ __device__ __forceinline__ fp shk_mfma_submul2(const fp& a, const fp& b, const s
   acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(nw1, b1, acc1, 0, 0, 0);
   acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(nw2, b2, acc2, 0, 0, 0);
   uint32_t r1[5], r2[5];
-  shk_norm16(acc1, r1);
-  shk_norm16(acc2, r2);
+  shk_norm16x2(acc1, acc2, r1, r2);
 #pragma unroll
   for (int i = 0; i < 5; ++i) shk_swap32(r1[i], r2[i]);
   // r1 = limbs 0..3 + carry into limb 4, r2 = limbs 4..7 + carry out (weight 2^256), all of this lane's own element

@@ -199,7 +199,8 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
       if (a.scale) v = fp_mul(v, fp_load(a.scale));
       fp_store(a.dst + th.obase + ((uint64_t)k << a.log_P), v);
     } else {
-      fp v = fp_mul(th.x[h], tw_lookup(a, th.j2 * k));
+      const fp tw = a.tw2 ? fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2) : tw_lookup(a, th.j2 * k);
+      fp v = fp_mul(th.x[h], tw);
       fp_store(a.dst + th.gbase + ((uint64_t)k << a.log_S), v);
     }
   }

@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
   constexpr int QMAX = LOG_R - 5 < 3 ? LOG_R - 5 : 3;   // top level of stage 2
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
 
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: twiddle-matrix addresses stay scalar
   const uint32_t c = lane & 31u, hb = lane >> 5;
   const uint32_t rho = 2u * wave + hb;  // row group of stage 1, and row block mu of stage 2
   const uint64_t col = ((uint64_t)blockIdx.x << 5) + c;

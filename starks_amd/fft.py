@@ -4,9 +4,15 @@
     NonBinaryFFT(field, root_of_unity).fft(poly) -> list ; .inv_fft(values) -> Poly
     mul_polys(a, b, root_of_unity) -> list            (unscaled, exactly like the reference)
 
-Supported: the MiMC prime p = 2^256 - 351*2^32 + 1 and roots of unity of power-of-two order (every STARK
-call site of the reference: stark.py:31-34,217-225,253-256, fri.py:207-208,260-261).  Anything else raises
-NotImplementedError -- there is deliberately no CPU fallback.
+The hot path -- the MiMC prime p = 2^256 - 351*2^32 + 1 with roots of unity of power-of-two order, i.e. every STARK
+call site of the reference (stark.py:31-34,217-225,253-256, fri.py:207-208,260-261) -- ALWAYS runs on the GPU through
+libstarkhip.so and raises when the library or the device is missing: there is no CPU fallback for it.
+
+Inputs the device code cannot represent at all -- another modulus (the reference's unit tests use Z/31,
+test_fft.py:98-113,132-149) or a root whose order is not a power of two (n = 6 there) -- are outside the hot path; for
+those `fft_1d` follows the reference's own recursion on the host (`_host_fft_1d`, a few lines of Python on field
+elements), so that the reference's unit tests run unchanged through this module.  It is never used for the MiMC field
+with a power-of-two order.
 """
 import ctypes
 
@@ -41,9 +47,58 @@ def ntt_bytes(data, n, root_of_unity, inverse=False, batch=1):
     return out.raw
 
 
+def _on_device(modulus, root_of_unity):
+    return int(modulus) == MIMC_P and _lib.order_of_root(root_of_unity) is not None
+
+
+def _host_simple_ft(vals, roots):
+    """starks/fft.py:287-300: the naive transform the reference uses below 5 points (and for odd factors)."""
+    L = len(roots)
+    out = []
+    for i in range(L):
+        last = 0
+        for j in range(L):
+            last += vals[j] * roots[(i * j) % L]
+        out.append(last)
+    return out
+
+
+def _host_fft(vals, roots):
+    """starks/fft.py:303-314"""
+    if len(vals) <= 4 or len(vals) % 2:
+        return _host_simple_ft(vals, roots)
+    L = _host_fft(vals[::2], roots[::2])
+    R = _host_fft(vals[1::2], roots[::2])
+    o = [0] * len(vals)
+    for i, (x, y) in enumerate(zip(L, R)):
+        y_times_root = y * roots[i]
+        o[i] = x + y_times_root
+        o[i + len(L)] = x - y_times_root
+    return o
+
+
+def _host_fft_1d(field, vals, modulus, root_of_unity, inv=False):
+    """starks/fft.py:316-331 on the host, ONLY for fields / orders the device code does not cover (see the module
+    docstring); element arithmetic is the field type's own."""
+    root_of_unity = field(root_of_unity)
+    rootz = [field(1), root_of_unity]
+    while rootz[-1] != field(1):
+        rootz.append(rootz[-1] * root_of_unity)
+        if len(rootz) > (1 << 16):
+            raise NotImplementedError("host transform: root order above 2^16 (use the MiMC field on the GPU)")
+    vals = [field(v) for v in vals]
+    if len(rootz) > len(vals) + 1:
+        vals = vals + [field(0)] * (len(rootz) - len(vals) - 1)
+    if inv:
+        invlen = field(len(vals)) ** (int(modulus) - 2)
+        return [x * invlen for x in _host_fft(vals, rootz[:0:-1])]
+    return _host_fft(vals, rootz[:-1])
+
+
 def fft_1d(field, vals, modulus, root_of_unity, inv=False):
     """starks/fft.py:316-331 -- the transform length is the order of root_of_unity; `vals` is zero-padded."""
-    _check_field(modulus)
+    if not _on_device(modulus, root_of_unity):
+        return _host_fft_1d(field, list(vals), modulus, root_of_unity, inv)
     n = _order(root_of_unity)
     vals = list(vals)
     out = ntt_bytes(_lib.to_wire(vals), n, int(root_of_unity), inverse=inv)

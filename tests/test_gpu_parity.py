@@ -142,9 +142,11 @@ def test_reference_call_sites_fft(sa):
     prod = sa.fft.mul_polys([F(v) for v in range(4)], [F(v) for v in range(4)], F(7) ** ((P - 1) // 512))
     assert [int(v) for v in prod[:16]] == g["mul_polys_0123"]["first16"]
     assert hashlib.sha256(wire(prod)).hexdigest() == g["mul_polys_0123"]["sha"]
-    with pytest.raises(NotImplementedError):  # mod-31 fields are outside the accelerated path
-        F31 = sa.pkg.IntegersModP(31)
-        sa.fft.fft_1d(F31, [0, 1, 2, 3], 31, F31(26))
+    # mod-31 / order-6 inputs (test_fft.py:98-113) are outside the accelerated field: host recursion, reference KAT
+    F31 = sa.pkg.IntegersModP(31)
+    assert [int(v) for v in sa.fft.fft_1d(F31, [0, 1, 2, 3], 31, F31(26))] == g["mod31_n6"]["fwd"]
+    with pytest.raises(NotImplementedError):  # mul_polys stays MiMC-only
+        sa.fft.mul_polys([F31(1)], [F31(1)], F31(26))
 
 
 def test_power_cycle(sa):
@@ -963,3 +965,18 @@ def test_bench_two_ranks_share_this_gpu(sa, args):
         assert line["check"]["roundtrip_ok"] is True and line["scaling"] == "weak"
     else:
         assert line["scaling"] == "strong" and line["unit"] == "proofs/s"
+
+
+def test_mfma_tile_passes_parity(sa, tmp_path):
+    """The matrix-core tile passes (csrc/ntt_mfma.hip, STARKHIP_NTT_PATH=mfma; the default is the integer-VALU passes):
+    the NTT golden vectors, every size against the oracle, the 2^22 digest and a FRI + STARK proof, in a child process."""
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, STARKHIP_NTT_PATH="mfma")
+    sel = ("test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or "
+           "test_randomized_ntt_differential or (test_ntt_large_digests_vs_oracle_fixture and 22) or test_lde_golden or "
+           "test_fri_proofs_golden or test_stark_proofs_golden or test_device_resident_pipeline")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
+                          "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

@@ -163,6 +163,25 @@ def test_stark_host_mirror_on_reference_proofs():
             S.verify_proof(bad, witness, boundary)
 
 
+def test_reference_fft_unit_tests_on_other_fields():
+    """The reference's own FFT unit tests on Z/31 with a 6th root of unity (test_fft.py:98-113, 132-149, 151-168): not
+    the accelerated field, so `fft_1d` follows the reference's recursion on the host; values from the live reference
+    (tests/golden/ntt.json:mod31_n6)."""
+    from starks_amd import IntegersModP
+    from starks_amd.fft import NonBinaryFFT, fft_1d
+    from starks_amd.polynomial import polynomials_over
+    g = load_golden("ntt.json")["mod31_n6"]
+    F = IntegersModP(31)
+    polys = polynomials_over(F).factory
+    poly = polys([0, 1, 2, 3])
+    w = F(3) ** ((31 - 1) // 6)
+    solver = NonBinaryFFT(F, w)
+    ev = solver.fft(poly)
+    assert len(ev) == 6 and [int(v) for v in ev] == g["fwd"] and all(isinstance(v, F) for v in ev)
+    assert solver.inv_fft(ev) == poly
+    assert [int(v) for v in fft_1d(F, [0, 1, 2, 3], 31, w)] == g["fwd"]
+
+
 def test_prover_input_shape_errors():
     """Short witness / input buffers and short boundary lists are refused on the host (the C side would read past them)."""
     from starks_amd import IntegersModP, stark
