@@ -195,7 +195,9 @@ def extras(dev, quick):
         w = root_of(n).to_bytes(32, "big")
         dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
         dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed), "fill")
-        ms = dev.timed(lambda: dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"), 10)
+        for _ in range(3):  # plan tables + clocks settled before the timed forward transforms
+            dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt")
+        ms = dev.timed(lambda: dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"), 20)
         # reference-independent pin: the forward digest against the C oracle's (tests/golden/ntt_large.json)
         whole = ctypes.create_string_buffer(32 * n)
         dev.ck(L.sh_dev_to_wire(ctx, dy, whole, n), "dl")
@@ -407,6 +409,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=32, help="c5: proofs per batched launch")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="ntt: skip the many-proof leg")
+    ap.add_argument("--no-single", action="store_true", help="ntt: skip the single-vector leg (profiling runs: keeps the "
+                    "kernel trace to the timed workload's launches)")
     ap.add_argument("--quick", action="store_true", help="smaller secondary legs / c5 shape")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
@@ -580,10 +584,10 @@ def main():
     alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
     achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for tf in ("r02_traffic.json", "r01_traffic.json"):
-        try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_traffic.sh)
+    for tf in ("r02_traffic_2p%d.json" % args.logn, "r01_traffic.json"):
+        try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_r02.sh)
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-            if args.logn == 20 and tj.get("vectors_per_step", 1) == B:
+            if tj.get("logn", 20) == args.logn and tj.get("vectors_per_step", 1) == B:
                 traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)" % tf
                 break
@@ -611,7 +615,7 @@ def main():
                      "note": "integer-VALU bound, not HBM bound; see DESIGN.md section 5"},
     }
     single_ms = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_single:
         # the literal configs[1]: the same transform pair on ONE vector (a launch's load / store phases are then exposed)
         single_ms = dev.timed(lambda: (dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"),
                                        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")), 50)

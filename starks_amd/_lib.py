@@ -56,8 +56,8 @@ def lib():
         "sh_sync": (i32, [c_p]),
         "sh_timer_start": (i32, [c_p]),
         "sh_timer_stop": (i32, [c_p, ctypes.POINTER(ctypes.c_float)]),
-        "sh_ntt": (i32, [c_p, u8p, u64, c_p, u64, u8p, i32]),
-        "sh_ntt_batch": (i32, [c_p, u8p, u64, c_p, u64, u32, u8p, i32]),
+        "sh_ntt": (i32, [c_p, c_p, u64, c_p, u64, u8p, i32]),
+        "sh_ntt_batch": (i32, [c_p, c_p, u64, c_p, u64, u32, u8p, i32]),
         "sh_mul_polys": (i32, [c_p, u8p, u64, u8p, u64, c_p, u64, u8p]),
         "sh_power_cycle": (i32, [c_p, u8p, u64, c_p]),
         "sh_lde": (i32, [c_p, u8p, c_p, u64, u32, u32, u8p]),
@@ -73,6 +73,8 @@ def lib():
         "sh_dev_download": (i32, [c_p, c_p, c_p, u64]),
         "sh_dev_upload": (i32, [c_p, u8p, c_p, u64]),
         "sh_dev_copy": (i32, [c_p, c_p, c_p, u64]),
+        "sh_host_alloc": (i32, [c_p, u64, pp]),
+        "sh_host_free": (i32, [c_p, c_p]),
         "sh_ntt_passes": (u32, [u64]),
         "sh_dev_download_2d": (i32, [c_p, c_p, u64, c_p, u64, u64]),
         "sh_dev_fill_seeded": (i32, [c_p, c_p, u64, u64]),
@@ -141,6 +143,28 @@ def check(rc, where):
         if _ctx is not None:
             detail = lib().sh_last_error(_ctx).decode()
         raise StarkHipError(rc, where, detail)
+
+
+class PinnedBuffer(object):
+    """`nbytes` of page-locked host memory (sh_host_alloc): a buffer the host-buffer entry points copy to and from the
+    GPU without the staging memcpy.  Usable wherever bytes-like data is passed (`buf.view` is a ctypes char array)."""
+
+    def __init__(self, nbytes):
+        self.ptr = ctypes.c_void_p()
+        check(lib().sh_host_alloc(ctx(), nbytes, ctypes.byref(self.ptr)), "sh_host_alloc")
+        self.nbytes = nbytes
+        self.view = (ctypes.c_char * nbytes).from_address(self.ptr.value)
+
+    def close(self):
+        if self.ptr:
+            lib().sh_host_free(ctx(), self.ptr)
+            self.ptr = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def to_wire(values, modulus=MIMC_P):

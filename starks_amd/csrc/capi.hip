@@ -172,10 +172,24 @@ int pin_wait(sh_ctx* c, int slot) {
   }
   return SH_OK;
 }
+// caller memory the DMA engines can reach directly (sh_host_alloc, hipHostMalloc / hipHostRegister): no staging copy
+bool host_is_pinned(const void* h) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, h) != hipSuccess) {
+    (void)hipGetLastError();  // an unregistered pointer is an "error" to this query, not to us
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
 // host (pageable) -> device through the pinned slots: the host memcpy of chunk i+1 overlaps the DMA of chunk i.
 // Returns once `h` has been consumed; the device copy completes in stream order.
 int h2d(sh_ctx* c, void* d, const void* h, size_t bytes) {
   if (bytes == 0) return SH_OK;
+  if (bytes >= ((size_t)64 << 10) && host_is_pinned(h)) {
+    HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return SH_OK;
+  }
   if (bytes < ((size_t)64 << 10)) {
     HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     return SH_OK;
@@ -197,7 +211,7 @@ int h2d(sh_ctx* c, void* d, const void* h, size_t bytes) {
 // device -> host (pageable); blocks until `h` is complete.
 int d2h(sh_ctx* c, void* h, const void* d, size_t bytes) {
   if (bytes == 0) return SH_OK;
-  if (bytes < ((size_t)64 << 10)) {
+  if (bytes < ((size_t)64 << 10) || host_is_pinned(h)) {
     HIP_TRY(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SH_OK;
@@ -1007,6 +1021,19 @@ int sh_dev_download(sh_ctx* c, const void* d_src, void* host_dst, uint64_t bytes
   if (!c || (!host_dst && bytes) || (!d_src && bytes)) return SH_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   return d2h(c, host_dst, d_src, bytes);
+}
+int sh_host_alloc(sh_ctx* c, uint64_t bytes, void** hptr) {
+  if (!c || !hptr) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipHostMalloc(hptr, bytes ? bytes : 32, hipHostMallocDefault));
+  return SH_OK;
+}
+int sh_host_free(sh_ctx* c, void* hptr) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipHostFree(hptr));
+  return SH_OK;
 }
 int sh_dev_copy(sh_ctx* c, const void* d_src, void* d_dst, uint64_t bytes) {
   if (!c || (bytes && (!d_src || !d_dst))) return SH_ERR_INVALID;

@@ -129,38 +129,39 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
       x[m] = active ? fp_load(a.src + gbase + ((uint64_t)i << a.log_S)) : fp_zero();
     }
   } else {
-    // rows are contiguous: lanes run along the row for the global load, the tile is transposed through LDS, CW rows
-    // (= tile columns) per round
-    constexpr int LOG_SEG = LOG_R < 6 ? LOG_R : 6;   // points of a row covered by one sweep of lanes
-    constexpr int SEG = 1 << LOG_SEG;
-    constexpr int ROWS_PER_SWEEP = THREADS / SEG;
-    constexpr int ELEMS = CW * R / THREADS;           // per thread per round
-    constexpr int SWEEPS_PER_ROW = R / SEG;
+    // rows are contiguous: lanes run along the row for the global load (all 16 loads of a thread are requested up
+    // front), then the tile is transposed through LDS, CW rows (= tile columns) per round
+    constexpr int ELEMS = CW * R / THREADS;  // per thread per round (= 8)
+    fp ld[NR * ELEMS];
+    static_for<NR * ELEMS>([&](auto ei) {
+      constexpr int e = decltype(ei)::value % ELEMS, k = decltype(ei)::value / ELEMS;
+      const uint32_t flat = (uint32_t)e * THREADS + tid;  // < CW * R: (row r_l inside the round, point i)
+      // a wave covers (part of) ONE row when R >= 64: its coordinates are wave-uniform (scalar arithmetic)
+      const uint32_t r_l = LOG_R >= 6 ? (uint32_t)__builtin_amdgcn_readfirstlane(flat >> LOG_R) : flat >> LOG_R;
+      const uint32_t i = flat & (R - 1);
+      const uint64_t rcol = ((uint64_t)blockIdx.x << 5) + (uint32_t)k * CW + r_l;
+      fp v = fp_zero();
+      if (rcol < a.total) {
+        uint64_t gb, ob;
+        row_coords<LOG_R>(a, rcol, &gb, &ob);
+        v = fp_load(a.src + gb + i);
+      }
+      ld[decltype(ei)::value] = v;
+    });
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       if (k > 0) __syncthreads();
-#pragma unroll
-      for (int e = 0; e < ELEMS; ++e) {
-        // sweep e covers rows [e / SWEEPS_PER_ROW ...]: thread -> (row r_l inside the round, point i)
-        const uint32_t flat = (uint32_t)e * THREADS + tid;           // < CW * R
-        const uint32_t r_l = flat >> LOG_R, i = flat & (R - 1);
-        const uint64_t rcol = ((uint64_t)blockIdx.x << 5) + (uint32_t)k * CW + r_l;
-        fp v = fp_zero();
-        if (rcol < a.total) {
-          uint64_t gb, ob;
-          row_coords<LOG_R>(a, rcol, &gb, &ob);
-          v = fp_load(a.src + gb + i);
-        }
-        lds_put_at(lds, win_slot<LOG_CW>(i, r_l), v);
-      }
+      static_for<ELEMS>([&](auto ei) {
+        constexpr int e = decltype(ei)::value;
+        const uint32_t flat = (uint32_t)e * THREADS + tid;
+        lds_put_at(lds, win_slot<LOG_CW>(flat & (R - 1), flat >> LOG_R), k == 0 ? ld[e] : ld[ELEMS + e]);
+      });
       __syncthreads();
       if ((c >> LOG_CW) == (uint32_t)k) {
 #pragma unroll
         for (int m = 0; m < 16; ++m) x[m] = lds_get_at(lds, win_slot<LOG_CW>((uint32_t)m * G + rho, c & (CW - 1)));
       }
     }
-    (void)ROWS_PER_SWEEP;
-    (void)SWEEPS_PER_ROW;
     __syncthreads();
   }
 

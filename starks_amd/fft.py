@@ -35,16 +35,23 @@ def _order(root_of_unity):
     return n
 
 
-def ntt_bytes(data, n, root_of_unity, inverse=False, batch=1):
-    """Wire-form fast path: `data` = batch * n_in 32-byte big-endian values -> batch * n outputs."""
-    n_in = len(data) // (32 * batch)
+def ntt_bytes(data, n, root_of_unity, inverse=False, batch=1, out=None):
+    """Wire-form fast path: `data` = batch * n_in 32-byte big-endian values -> batch * n outputs.  `data` may be bytes
+    or a `_lib.PinnedBuffer`; with `out` (a PinnedBuffer of 32 * n * batch bytes) the result is written there and `out`
+    is returned -- both ends then skip the staging copy (include/starkhip.h, host-buffer API)."""
+    pinned_in = isinstance(data, _lib.PinnedBuffer)
+    nbytes = data.nbytes if pinned_in else len(data)
+    n_in = nbytes // (32 * batch)
     if n_in > n:
         raise ValueError("more input values (%d) than the order of the root of unity (%d)" % (n_in, n))
-    out = ctypes.create_string_buffer(32 * n * batch)
-    rc = _lib.lib().sh_ntt_batch(_lib.ctx(), data, n_in, out, n, batch, int(root_of_unity).to_bytes(32, "big"),
+    src = data.ptr if pinned_in else ctypes.cast(ctypes.c_char_p(bytes(data) if not isinstance(data, bytes) else data), ctypes.c_void_p)
+    dst = out.ptr if out is not None else ctypes.create_string_buffer(32 * n * batch)
+    if out is not None and out.nbytes < 32 * n * batch:
+        raise ValueError("output buffer too small")
+    rc = _lib.lib().sh_ntt_batch(_lib.ctx(), src, n_in, dst, n, batch, int(root_of_unity).to_bytes(32, "big"),
                                  1 if inverse else 0)
     _lib.check(rc, "sh_ntt_batch")
-    return out.raw
+    return out if out is not None else dst.raw
 
 
 def _on_device(modulus, root_of_unity):

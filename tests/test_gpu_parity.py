@@ -980,3 +980,19 @@ def test_mfma_tile_passes_parity(sa, tmp_path):
                           "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def test_pinned_host_buffers_skip_staging(sa):
+    """sh_host_alloc buffers go through the host-buffer entry points without the staging copy and give the same bytes."""
+    n = 1 << 14
+    w = root_of(n)
+    data = wire(seeded(77, i) for i in range(n))
+    want = sa.fft.ntt_bytes(data, n, w)
+    src, dst = sa.lib.PinnedBuffer(32 * n), sa.lib.PinnedBuffer(32 * n)
+    src.view[:] = data
+    assert sa.fft.ntt_bytes(src, n, w, out=dst) is dst
+    assert bytes(dst.view) == want
+    back = sa.fft.ntt_bytes(dst, n, w, inverse=True)
+    assert back == data
+    src.close()
+    dst.close()

@@ -16,14 +16,16 @@ def durations(root):
 if __name__ == "__main__":
     fdir, wdir, sdir, out = sys.argv[1:5]
     vectors = int(sys.argv[5]) if len(sys.argv) > 5 else 8  # bench.py --batch of the profiled command
+    logn = int(sys.argv[6]) if len(sys.argv) > 6 else 20
     F, W, D = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE"), durations(sdir)
-    res = {"workload": "bench.py default: 2^20-point NTT + inverse NTT, %d vectors per step" % vectors,
-           "vectors_per_step": vectors, "unit": "bytes per launch",
+    res = {"workload": "bench.py --logn %d --batch %d: 2^%d-point NTT + inverse NTT, %d vectors per step" % (logn, vectors, logn, vectors),
+           "logn": logn, "vectors_per_step": vectors, "unit": "bytes per launch",
+           "algorithmic_bytes_per_launch": 64.0 * (1 << logn) * vectors / 3,
            "correction": "2*FETCH_SIZE + WRITE_SIZE, counters in KiB (gfx950: FETCH_SIZE = 1/2 of a wide coalesced stream)",
            "kernels": {}}
     tot_b = tot_n = 0
     for k in F:
-        if "ntt_pass" not in k:
+        if "ntt_pass" not in k and "ntt_ctile" not in k:
             continue
         fb = 2 * 1024 * sum(F[k]) / len(F[k])
         wb = 1024 * sum(W[k]) / len(W[k])
