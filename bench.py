@@ -144,9 +144,9 @@ class ProofShard:
             self.dev.free(p)
 
 
-def gather_headers(local, total, rank, world, dist, tdev):
+def gather_headers(local, total, rank, world, dist, tdev, force=False):
     """all_gather of the fixed-size proof headers (the only exchange of the many-proof path)."""
-    if world == 1:
+    if world == 1 and not force:
         return list(local)
     import torch
     from starks_amd.batch import shard
@@ -352,6 +352,15 @@ def cpu_baseline_c5(steps, ext=8):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def emit(line):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -386,10 +395,10 @@ def dry_run(args, rank, world):
     allh = gather_headers(local, args.units, rank, world, dist, "cpu")
     ok = allh == [hashlib.sha256(b"unit-%d" % j).digest() * 2 for j in range(args.units)]
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "value": None, "unit": None, "n_gpus": world, "steps": args.steps,
+        emit({"metric": "dry-run", "value": None, "unit": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "data": "none (plumbing only, no GPU work)",
                           "config": {"workload": args.workload, "units": args.units}, "gather_ok": ok,
-                          "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)]}))
+                          "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)]})
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -434,6 +443,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # stdout carries exactly ONE line, the JSON of rank 0: whatever libraries print there (RCCL's version banner at
+    # communicator creation, ...) goes to stderr instead
+    sys.stdout.flush()
+    global _REAL_STDOUT
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.dry_run:
         sys.exit(dry_run(args, rank, world))
 
@@ -445,7 +460,9 @@ def main():
     os.environ["STARKHIP_DEVICE"] = str(dev_index)
     torch.cuda.set_device(dev_index)
     tdev = "cuda" if args.backend == "nccl" else "cpu"  # where the tiny control tensors live
-    if world > 1:
+    # BENCH_FORCE_DIST=1: run the collectives even with one rank (rehearses the RCCL calls on a one-GPU box)
+    use_dist = world > 1 or (os.environ.get("BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -457,19 +474,19 @@ def main():
     def fence():
         dev.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     def max_over_ranks(dt):
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def all_ok(flag):
         t = torch.tensor([1 if flag else 0], device=tdev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
@@ -481,13 +498,13 @@ def main():
         heads = None
         for _ in range(warm_k):
             sh.prove_all()
-            gather_headers(sh.headers(), args.units, rank, world, dist, tdev)
+            gather_headers(sh.headers(), args.units, rank, world, dist, tdev, use_dist)
         fence()
         dev.ck(L.sh_timer_start(ctx), "timer")
         t0 = time.perf_counter()
         for _ in range(steps_k):
             sh.prove_all()
-            heads = gather_headers(sh.headers(), args.units, rank, world, dist, tdev)  # the step's only exchange
+            heads = gather_headers(sh.headers(), args.units, rank, world, dist, tdev, use_dist)  # the step's only exchange
         ev = ctypes.c_float()
         dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev)), "timer")
         fence()
@@ -532,8 +549,8 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_c5(steps)
         if rank == 0:
-            print(json.dumps(line))
-        if world > 1:
+            emit(line)
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -643,8 +660,8 @@ def main():
                 line["ntt_large_elements_per_s"] = line["extra"][big[0]]["elements_per_s"]
                 line["ntt_large_hbm_frac"] = line["extra"][big[0]]["hbm_frac"]
     if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
+        emit(line)
+    if use_dist:
         dist.destroy_process_group()
 
 
