@@ -16,7 +16,7 @@ configs[1] figure and the metric's second half (FRI commit of a 2^20-step trace)
 
 Workload `c5` (BASELINE configs[4]): `--units` (512) independent 2^16-step MiMC STARK proofs (STARK.mk_proof,
 stark.py:233-279; unit j = test_stark.py:265-293 started from 3 + j), sharded over the ranks by proof index
-(starks_amd/batch.py:shard), 32 proofs per batched launch; a step = the whole batch once; `value` = proofs/s; strong
+(starks_amd/batch.py:shard), 64 proofs per batched launch; a step = the whole batch once; `value` = proofs/s; strong
 scaling; the only exchange is one all_gather of the 64-byte proof headers (m_root | l_root) per step (RCCL).  Every run of
 the default workload also runs one such step after its timed region and reports it under `c5` / `c5_proofs_per_s`, so
 that the driver's N = 1, 2, 4, 8 runs record the proofs/s curve too.
@@ -415,7 +415,7 @@ def main():
                     "trace: one launch sequence covers all of them)")
     ap.add_argument("--units", type=int, default=None, help="c5: proofs in the batch (512; 16 with --quick)")
     ap.add_argument("--logsteps", type=int, default=None, help="c5: log2 trace length (16; 10 with --quick)")
-    ap.add_argument("--chunk", type=int, default=32, help="c5: proofs per batched launch")
+    ap.add_argument("--chunk", type=int, default=64, help="c5: proofs per batched launch")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="ntt: skip the many-proof leg")
     ap.add_argument("--no-single", action="store_true", help="ntt: skip the single-vector leg (profiling runs: keeps the "

@@ -471,9 +471,17 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
 }
 
 // d_out = NTT(d_in) over plan->root; [batch][n] limb form; d_in may equal d_out.
-int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch) {
+// n_in != 0: d_in holds n_in <= n elements per vector ([batch][n_in]) and stands for its zero-padded extension
+// (fft.py:323-324); d_in must then not alias d_out.  The first pass reads the short source and takes the rest as zeros.
+int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, uint64_t n_in = 0) {
   const uint64_t n = pl->n;
   if (batch == 0) return SH_OK;
+  if (n_in >= n) n_in = 0;
+  if (n_in && (pl->log_n <= 1 || (use_mfma_path() && pl->radix[0] >= 5))) {  // paths without the short-source load
+    HIP_TRY(c, shk_pad_copy(d_in, d_out, n_in, n, batch, c->stream));
+    d_in = d_out;
+    n_in = 0;
+  }
   if (pl->log_n <= 1) {
     HIP_TRY(c, shk_launch_ntt_tiny(d_in, d_out, (uint32_t)n, batch, n == 2 ? pl->scale : nullptr, c->stream));
     return SH_OK;
@@ -493,6 +501,7 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch) {
     memset(&a, 0, sizeof a);
     a.log_n = (uint32_t)pl->log_n;
     a.wR = pl->wR[d];
+    a.src_n = d == 0 ? n_in : 0;
     const bool last = d + 1 == m;
     if (!last) {
       a.src = src;
@@ -882,8 +891,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   HIP_TRY(c, shk_stark_interp(d_wit, d_inputs, steps, (uint32_t)cols, inv_last_m1, iab, c->stream));
   // trace polynomials and their evaluations: the low-degree extension (stark.py:27-36, 253-256)
   SH_TRY(run_ntt(c, inv_s, d_wit, d_wit, (uint32_t)cols));
-  HIP_TRY(c, shk_pad_copy(d_wit, P, steps, n, (uint32_t)cols, c->stream));
-  SH_TRY(run_ntt(c, fwd_n, P, P, (uint32_t)cols));
+  SH_TRY(run_ntt(c, fwd_n, d_wit, P, (uint32_t)cols, steps));  // the zero padding of fft_1d is implicit (fft.py:323-324)
   // Q = X P'(X) on the trace points, for the quotients' values there
   HIP_TRY(c, shk_stark_qprep(d_wit, Q, steps, cols, c->stream));
   SH_TRY(run_ntt(c, fwd_s, Q, Q, (uint32_t)cols));
@@ -1094,8 +1102,7 @@ int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t e
   fp* t = reinterpret_cast<fp*>(d_trace);
   fp* x = reinterpret_cast<fp*>(d_out);
   SH_TRY(run_ntt(c, inv1, t, t, cols));                                  // stark.py:27-36
-  HIP_TRY(c, shk_pad_copy(t, x, steps, n, cols, c->stream));             // zero padding of fft_1d (fft.py:323-324)
-  return run_ntt(c, fwd2, x, x, cols);                                   // stark.py:253-256
+  return run_ntt(c, fwd2, t, x, cols, steps);                            // stark.py:253-256; fft_1d's zero padding implicit
 }
 int sh_dev_merkelize(sh_ctx* c, const void* d_values, uint64_t n, uint32_t batch, void* d_nodes) {
   if (!c || !d_values || !d_nodes || !is_pow2(n) || n < 4 || batch == 0) return SH_ERR_INVALID;
@@ -1219,8 +1226,7 @@ int sh_lde(sh_ctx* c, const uint8_t* trace, uint8_t* out, uint64_t steps, uint32
   SH_TRY(run_ntt(c, inv1, t, t, cols));  // trace polynomial coefficients (stark.py:27-36)
   void* x = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_X, (size_t)cols * n * sizeof(fp), &x));
-  HIP_TRY(c, shk_pad_copy(t, reinterpret_cast<fp*>(x), steps, n, cols, c->stream));
-  SH_TRY(run_ntt(c, fwd2, reinterpret_cast<fp*>(x), reinterpret_cast<fp*>(x), cols));  // stark.py:253-256
+  SH_TRY(run_ntt(c, fwd2, t, reinterpret_cast<fp*>(x), cols, steps));  // stark.py:253-256
   return download_wire(c, reinterpret_cast<fp*>(x), out, (uint64_t)cols * n);
 }
 

@@ -22,6 +22,8 @@ struct NttPassArgs {
   uint32_t ndig;
   uint32_t dig_log[3];
   const fp* scale;    // row pass: optional factor applied to every output (n^-1 of a one-pass inverse)
+  uint64_t src_n;     // first pass only: the source holds src_n <= n elements per vector, the rest of each vector is zero
+                      // (fft_1d's zero padding, fft.py:323-324, never materialised); 0 = the source holds n per vector
   uint32_t debug;     // diagnostic (SHK_STAMPS) builds only: 1 = this pass records its phase stamps
   const fp* tw2;      // MFMA column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k); else null
   const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null

@@ -65,6 +65,7 @@ struct TileThread {
   uint64_t gbase;  // global element offset of (this thread's column/row, i = 0)
   uint64_t j2;     // column pass: column index inside the prefix block
   uint64_t obase;  // row pass: output offset of k = 0
+  uint64_t sbase;  // zero-padded source (a.src_n != 0): element offset of (this column/row, i = 0) in the short source
 };
 
 // Register group g: fetch 4 elements (global memory for g == 0, LDS otherwise), do its butterfly levels,
@@ -111,9 +112,11 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
       }
       th.gbase = (b << a.log_n) + ((uint64_t)p << LOG_R);
       th.obase = (b << a.log_n) + acc;
+      th.sbase = b * a.src_n;  // used by one-pass transforms only (p = 0)
     } else {
       th.j2 = col & ((1ull << a.log_S) - 1);
       th.gbase = ((col >> a.log_S) << (LOG_R + a.log_S)) + th.j2;
+      th.sbase = (col >> a.log_S) * a.src_n + th.j2;  // first pass: P = 1, col >> log_S is the vector index
     }
   }
 
@@ -122,7 +125,10 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   for (int h = 0; h < 4; ++h) {
     const uint32_t i = th.ibase | ((uint32_t)h << beta);
     if (g == 0) {
-      if (th.active) {
+      if (th.active && a.src_n) {  // zero-padded source: points at or beyond src_n are zero and are not read
+        const uint64_t off = LAST ? (uint64_t)i : ((uint64_t)i << a.log_S);
+        th.x[h] = off + (LAST ? 0 : th.j2) < a.src_n ? fp_load(a.src + th.sbase + off) : fp_zero();
+      } else if (th.active) {
         th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
       } else {
         th.x[h] = fp_zero();
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
   const uint32_t tid = threadIdx.x;
   const uint64_t tile0 = (uint64_t)blockIdx.x << LOG_T;
   TileThread th;
-  th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0;
+  th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0; th.sbase = 0;
   ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
   if constexpr (G > 1) ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
   if constexpr (G > 2) ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
