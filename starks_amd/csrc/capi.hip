@@ -660,7 +660,7 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
 
 // FRI commit on device-resident coefficients; see starkhip.h for the layout.
 int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], uint64_t maxdeg_plus_1,
-            uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* d_proof) {
+            uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* d_proof, uint64_t n_coeffs = 0) {
   if (!d_coeffs || !d_proof || batch == 0 || !is_pow2(n)) return SH_ERR_INVALID;
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, false, &pl));
@@ -668,7 +668,7 @@ int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], u
   FriBuffers fb;
   SH_TRY(fri_buffers(c, n, batch, samples, &fb));
   // values = fft(f) over the whole domain (fri.py:207-208)
-  SH_TRY(run_ntt(c, pl, d_coeffs, fb.vals, batch));
+  SH_TRY(run_ntt(c, pl, d_coeffs, fb.vals, batch, n_coeffs));  // n_coeffs != 0: [batch][n_coeffs], zero padding implicit
   return fri_rounds(c, pl, fb, n, maxdeg_plus_1, exclude, samples, batch, d_proof,
                     fri_proof_len(n, maxdeg_plus_1, samples), false);
 }
@@ -1160,6 +1160,21 @@ static int upload_padded(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint64_t n
   *out = reinterpret_cast<fp*>(x);
   return SH_OK;
 }
+// 0 < n_in < n: the values as they are ([batch][n_in] in WS_Y, a slot no FRI / NTT driver touches); the transform's first pass takes the zero padding as
+// implicit (run_ntt's n_in).  Otherwise the padded array of upload_padded, *n_short = 0.
+static int upload_short(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint64_t n, uint32_t batch, int slot, fp** out,
+                        uint64_t* n_short) {
+  *n_short = 0;
+  if (n_in == 0 || n_in >= n) return upload_padded(c, in, n_in, n, batch, slot, out);
+  void *w = nullptr, *y = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)batch * n * 32, &w));  // sized for the n-point result's download as well
+  SH_TRY(ws_get(c, sh_ctx::WS_Y, (size_t)batch * n_in * sizeof(fp), &y));
+  SH_TRY(h2d(c, w, in, (size_t)batch * n_in * 32));
+  HIP_TRY(c, shk_wire_to_limb(reinterpret_cast<uint8_t*>(w), reinterpret_cast<fp*>(y), (uint64_t)batch * n_in, c->stream));
+  *out = reinterpret_cast<fp*>(y);
+  *n_short = n_in;
+  return SH_OK;
+}
 static int download_wire(sh_ctx* c, const fp* d, uint8_t* out, uint64_t count) {
   void* w = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)count * 32, &w));
@@ -1175,8 +1190,16 @@ int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
   fp* x = nullptr;
-  SH_TRY(upload_padded(c, in, n_in, n, batch, sh_ctx::WS_X, &x));
-  SH_TRY(run_ntt(c, pl, x, x, batch));
+  uint64_t n_short = 0;
+  SH_TRY(upload_short(c, in, n_in, n, batch, sh_ctx::WS_X, &x, &n_short));
+  if (n_short) {
+    void* y = nullptr;
+    SH_TRY(ws_get(c, sh_ctx::WS_X, (size_t)batch * n * sizeof(fp), &y));
+    SH_TRY(run_ntt(c, pl, x, reinterpret_cast<fp*>(y), batch, n_short));  // fft.py:323-324, zeros not materialised
+    x = reinterpret_cast<fp*>(y);
+  } else {
+    SH_TRY(run_ntt(c, pl, x, x, batch));
+  }
   return download_wire(c, x, out, (uint64_t)batch * n);
 }
 int sh_ntt(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t n, const uint8_t root[32], int inverse) {
@@ -1305,10 +1328,11 @@ int sh_fri_prove(sh_ctx* c, const uint8_t* coeffs, uint64_t n_coeffs, uint64_t n
   const uint64_t stride = fri_proof_len(n, maxdeg_plus_1, samples);
   if (proof_cap < stride * batch) return SH_ERR_TOO_SMALL;
   fp* x = nullptr;
-  SH_TRY(upload_padded(c, coeffs, n_coeffs, n, batch, sh_ctx::WS_X, &x));
+  uint64_t n_short = 0;
+  SH_TRY(upload_short(c, coeffs, n_coeffs, n, batch, sh_ctx::WS_X, &x, &n_short));
   void* dp = nullptr;
   SH_TRY(ws_get(c, sh_ctx::WS_PROOF, (size_t)stride * batch, &dp));
-  SH_TRY(run_fri(c, x, n, root, maxdeg_plus_1, exclude, samples, batch, reinterpret_cast<uint8_t*>(dp)));
+  SH_TRY(run_fri(c, x, n, root, maxdeg_plus_1, exclude, samples, batch, reinterpret_cast<uint8_t*>(dp), n_short));
   return d2h(c, proof, dp, (size_t)stride * batch);
 }
 

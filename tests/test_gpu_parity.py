@@ -974,7 +974,7 @@ def test_mfma_tile_passes_parity(sa, tmp_path):
     from conftest import ROOT
     env = dict(os.environ, STARKHIP_NTT_PATH="mfma")
     sel = ("test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or "
-           "test_randomized_ntt_differential or (test_ntt_large_digests_vs_oracle_fixture and 22) or test_lde_golden or "
+           "test_randomized_ntt_differential or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or "
            "test_fri_proofs_golden or test_stark_proofs_golden or test_device_resident_pipeline")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
                           "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
