@@ -106,8 +106,11 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: twiddle-matrix addresses stay scalar
   const uint32_t c = lane & 31u, hb = lane >> 5;
   const uint32_t rho = 2u * wave + hb;  // row group of stage 1, and row block mu of stage 2
-  const uint64_t col = ((uint64_t)blockIdx.x << 5) + c;
-  const bool active = col < a.total;
+  const uint64_t col_raw = ((uint64_t)blockIdx.x << 5) + c;
+  const bool active = col_raw < a.total;
+  // columns past the end (partial last tile) compute on a copy of the last valid column and store nothing: every load is
+  // unconditional and in bounds, no zero-fill branches
+  const uint64_t col = active ? col_raw : a.total - 1;
   const shk_v16i cinit = shk_mfma_cinit(lane);
   const TwMat* mats = reinterpret_cast<const TwMat*>(a.mats);
 
@@ -126,7 +129,7 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const uint32_t i = (uint32_t)m * G + rho;
-      x[m] = active ? fp_load(a.src + gbase + ((uint64_t)i << a.log_S)) : fp_zero();
+      x[m] = fp_load(a.src + gbase + ((uint64_t)i << a.log_S));
     }
   } else {
     // rows are contiguous: lanes run along the row for the global load (all 16 loads of a thread are requested up
@@ -139,15 +142,13 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
       // a wave covers (part of) ONE row when R >= 64: its coordinates are wave-uniform (scalar arithmetic)
       const uint32_t r_l = LOG_R >= 6 ? (uint32_t)__builtin_amdgcn_readfirstlane(flat >> LOG_R) : flat >> LOG_R;
       const uint32_t i = flat & (R - 1);
-      const uint64_t rcol = ((uint64_t)blockIdx.x << 5) + (uint32_t)k * CW + r_l;
-      fp v = fp_zero();
-      if (rcol < a.total) {
-        uint64_t gb, ob;
-        row_coords<LOG_R>(a, rcol, &gb, &ob);
-        v = fp_load(a.src + gb + i);
-      }
-      ld[decltype(ei)::value] = v;
+      uint64_t rcol = ((uint64_t)blockIdx.x << 5) + (uint32_t)k * CW + r_l;
+      if (rcol >= a.total) rcol = a.total - 1;  // clamped: loaded, never stored
+      uint64_t gb, ob;
+      row_coords<LOG_R>(a, rcol, &gb, &ob);
+      ld[decltype(ei)::value] = fp_load(a.src + gb + i);
     });
+    STAMP(6);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       if (k > 0) __syncthreads();

@@ -19,13 +19,16 @@ print("passes:", L.sh_ntt_passes(n), " recorded pass:", os.environ.get("STARKHIP
 buf = (ctypes.c_ulonglong * (8 * 1024))()
 L.sh_debug_stamps.argtypes = [ctypes.c_void_p]
 assert L.sh_debug_stamps(buf) == 0
-st = [[buf[k * 1024 + b] for b in range(1024)] for k in range(6)]
+st = [[buf[k * 1024 + b] for b in range(1024)] for k in range(7)]
 nb = sum(1 for b in range(1024) if st[5][b] > st[0][b] > 0)
 names = ["load", "stage1", "exchange", "stage2", "twiddle+store"]
 import statistics
 for k in range(5):
     d = [st[k + 1][b] - st[k][b] for b in range(nb) if st[k + 1][b] > st[k][b]]
     print("%-14s median %8.0f  min %8.0f  max %8.0f  (ticks of s_memtime, %d workgroups)" % (names[k], statistics.median(d), min(d), max(d), len(d)))
+d = [st[6][b] - st[0][b] for b in range(nb) if st[6][b] > st[0][b]]
+if d:
+    print("%-14s median %8.0f  (row pass: address arithmetic + issue of the 16 global loads, part of `load`)" % ("  loads issued", statistics.median(d)))
 tot = [st[5][b] - st[0][b] for b in range(nb)]
 print("%-14s median %8.0f" % ("whole tile", statistics.median(tot)))
 starts = sorted(st[0][b] for b in range(nb))
