@@ -182,6 +182,41 @@ def test_reference_fft_unit_tests_on_other_fields():
     assert [int(v) for v in fft_1d(F, [0, 1, 2, 3], 31, w)] == g["fwd"]
 
 
+def test_twiddle_matrix_images(tmp_path):
+    """The MFMA operand images of the matrix-core NTT passes (csrc/mfma_tw.cuh:shk_build_twmat, host code): for every
+    byte k of the multiplicand, the 32 signed digits stored for it sum to w * 256^k (and to -w * 256^k) modulo p, every
+    digit fits an i8, and the (lane, byte) placement is the one the kernels assume (output row i = byte position rho(i))."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "twmat_dump.cpp")
+    exe = tmp_path / "twmat_dump"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "--offload-arch=gfx950", "-std=c++17", "-I",
+                           os.path.join(ROOT, "starks_amd", "csrc"), src, "-o", str(exe)], stderr=subprocess.DEVNULL)
+    ws = [1, P - 1, 2, 0x80, int("7f" * 32, 16), int("80" * 32, 16) % P, pow(7, (P - 1) // 256, P),
+          pow(7, (P - 1) // (1 << 24), P), 0x0123456789abcdef << 190, P - 12345]
+    out = subprocess.check_output([str(exe)] + ["%064x" % w for w in ws]).decode().split()
+    assert len(out) == len(ws)
+
+    def rho(i):
+        return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3)
+
+    for w, line in zip(ws, out):
+        img = bytes.fromhex(line)
+        assert len(img) == 2048
+        for half, target in ((img[:1024], w), (img[1024:], (P - w) % P)):
+            # lane = i + 32 h holds, at byte j, the digit of position rho(i) of the column kappa = 16 h + j
+            digits = [[0] * 32 for _ in range(32)]  # [kappa][position]
+            for lane in range(64):
+                i, h = lane & 31, lane >> 5
+                for j in range(16):
+                    b = half[16 * lane + j]
+                    digits[16 * h + j][rho(i)] = b - 256 if b >= 128 else b
+            assert sorted(rho(i) for i in range(32)) == list(range(32))
+            for kappa in range(32):
+                val = sum(d << (8 * m) for m, d in enumerate(digits[kappa]))
+                assert (val - target * 256 ** kappa) % P == 0, (hex(w), kappa)
+                assert -128 * ((256**32 - 1) // 255) <= val <= 127 * ((256**32 - 1) // 255)
+
+
 def test_prover_input_shape_errors():
     """Short witness / input buffers and short boundary lists are refused on the host (the C side would read past them)."""
     from starks_amd import IntegersModP, stark
