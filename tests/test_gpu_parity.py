@@ -996,3 +996,41 @@ def test_pinned_host_buffers_skip_staging(sa):
     assert back == data
     src.close()
     dst.close()
+
+
+def test_two_contexts_in_one_process(sa, oracle):
+    """Contexts are independent (include/starkhip.h): a second sh_ctx on the same device, interleaved with the process-wide
+    one, gives the same transforms and proofs; destroying it leaves the first one working."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    other = ctypes.c_void_p()
+    assert L.sh_ctx_create(0, ctypes.byref(other)) == 0
+    n = 1 << 12
+    w = root_of(n).to_bytes(32, "big")
+    data = wire(seeded(5, i) for i in range(n))
+    want = oracle.c.fft_bytes(data, n, root_of(n))
+    outs = []
+    for c in (ctx, other, ctx, other):
+        out = ctypes.create_string_buffer(32 * n)
+        assert L.sh_ntt(c, data, n, out, n, w, 0) == 0
+        outs.append(out.raw)
+    assert all(o == want for o in outs)
+    # a FRI commit on the second context while the first holds device-resident data
+    dx = ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dx)) == 0
+    assert L.sh_dev_fill_seeded(ctx, dx, n, 9) == 0
+    steps = n // 8
+    coeffs = wire(seeded(6, i) for i in range(steps))
+    plen = int(L.sh_fri_proof_len(n, steps, 40))
+    proof = ctypes.create_string_buffer(plen)
+    assert L.sh_fri_prove(other, coeffs, steps, n, w, steps, 8, 40, 1, proof, plen) == 0
+    assert proof.raw == oracle.c.fri_prove_flat(coeffs, root_of(n), steps, 8, 40, n=n)
+    host = ctypes.create_string_buffer(32 * n)
+    assert L.sh_dev_to_wire(ctx, dx, host, n) == 0
+    assert host.raw == wire(seeded(9, i) for i in range(n))
+    assert L.sh_ctx_trim(other) == 0
+    L.sh_ctx_destroy(other)
+    assert L.sh_dev_ntt(ctx, dx, dx, n, 1, w, 0) == 0
+    assert L.sh_dev_to_wire(ctx, dx, host, n) == 0
+    assert host.raw == oracle.c.fft_bytes(wire(seeded(9, i) for i in range(n)), n, root_of(n))
+    assert L.sh_dev_free(ctx, dx) == 0
