@@ -38,30 +38,67 @@ __device__ __forceinline__ void shk_swap32(uint32_t& v, uint32_t& u) {
   v = r[0];
   u = r[1];
 }
-__device__ __forceinline__ uint64_t shk_mad64(uint32_t a, uint32_t k, uint64_t c) {
+// Accumulator offsets.  Row j of a product is a signed sum (|s_j| < 2^23); adding O_j = 2^20 + delta_j, where
+// delta = -(2^20 * (2^256 - 1) / 255) mod p (little-endian bytes 17, 16, 240, 239, 160, 232, 217, then 239 for the remaining
+// 25) makes every row non-negative without changing the residue: sum_j O_j 2^(8j) == 0 (mod p).  Rather than starting the
+// MFMA chain from a 16-register block of offsets, the chain starts from zero and the offsets of a limb's four rows,
+// K_m = sum_k O_(4m+k) 2^(8k), enter as the 64-bit addend of the first v_mad_i64_i32 of that limb (6 registers).
+struct shk_kinit {
+  uint64_t k0, k1, k23;  // limbs 0, 1 (differ between the lane halves) and limbs 2, 3
+};
+__device__ __forceinline__ shk_kinit shk_mfma_kinit(uint32_t lane) {
+  const bool up = lane >= 32;
+  const uint64_t K = (1ull << 20) * 0x01010101ull;
+  shk_kinit k;
+  k.k0 = K + (up ? 0xefefefefull : 0xeff01011ull);
+  k.k1 = K + (up ? 0xefefefefull : 0xefd9e8a0ull);
+  k.k23 = K + 0xefefefefull;
+  return k;
+}
+__device__ __forceinline__ uint64_t shk_mad64s(uint32_t a, uint32_t k, uint64_t c) {
   uint64_t d;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
   return d;
 }
-// 16 non-negative partial sums (< 2^22) at byte spacing -> 4 limbs + carry (< 2^15), for the two accumulators of a
-// butterfly at once: the two carry chains are independent, so their dependent v_mad_u64_u32 alternate (`asm volatile`
-// keeps the order) and neither waits on its own previous result
-__device__ __forceinline__ uint64_t shk_mad64v(uint32_t a, uint32_t k, uint64_t c) {
+// `asm volatile` keeps the order: two independent carry chains alternate, so neither waits on its own previous result
+__device__ __forceinline__ uint64_t shk_mad64sv(uint32_t a, uint32_t k, uint64_t c) {
   uint64_t d;
-  asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
+  asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c) : "vcc");
   return d;
 }
-__device__ __forceinline__ void shk_norm16x2(const shk_v16i& s1, const shk_v16i& s2, uint32_t o1[5], uint32_t o2[5]) {
+// 16 signed row sums at byte spacing (+ offsets) -> 4 limbs + carry (< 2^16)
+__device__ __forceinline__ void shk_norm16k(const shk_v16i& s, const shk_kinit& kc, uint32_t out[5]) {
+  uint32_t cin = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    // limb 0 starts with plain arithmetic on purpose: the hazard recogniser does not look inside inline asm, and the
+    // first reader of an MFMA result must be an instruction it sees (it then inserts the wait states for the whole block)
+    const uint32_t e = (uint32_t)s[4 * m] + cin;  // |s| < 2^23, cin < 2^24
+    uint64_t t = m == 0 ? kc.k0 + (uint64_t)(int64_t)(int32_t)e : shk_mad64s(e, 1u, m == 1 ? kc.k1 : kc.k23);
+    t = shk_mad64s((uint32_t)s[4 * m + 1], 1u << 8, t);
+    t = shk_mad64s((uint32_t)s[4 * m + 2], 1u << 16, t);
+    t = shk_mad64s((uint32_t)s[4 * m + 3], 1u << 24, t);
+    out[m] = (uint32_t)t;
+    cin = (uint32_t)(t >> 32);
+  }
+  out[4] = cin;
+}
+// the same for the two accumulators of a whole-form butterfly at once
+__device__ __forceinline__ void shk_norm16x2k(const shk_v16i& s1, const shk_v16i& s2, const shk_kinit& kc, uint32_t o1[5],
+                                              uint32_t o2[5]) {
   uint32_t c1 = 0, c2 = 0;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
+    const uint64_t k = m == 0 ? kc.k0 : m == 1 ? kc.k1 : kc.k23;
     const uint32_t e1 = (uint32_t)s1[4 * m] + c1, e2 = (uint32_t)s2[4 * m] + c2;
-    uint64_t t1 = shk_mad64v((uint32_t)s1[4 * m + 1], 1u << 8, (uint64_t)e1);
-    uint64_t t2 = shk_mad64v((uint32_t)s2[4 * m + 1], 1u << 8, (uint64_t)e2);
-    t1 = shk_mad64v((uint32_t)s1[4 * m + 2], 1u << 16, t1);
-    t2 = shk_mad64v((uint32_t)s2[4 * m + 2], 1u << 16, t2);
-    t1 = shk_mad64v((uint32_t)s1[4 * m + 3], 1u << 24, t1);
-    t2 = shk_mad64v((uint32_t)s2[4 * m + 3], 1u << 24, t2);
+    uint64_t t1 = m == 0 ? k + (uint64_t)(int64_t)(int32_t)e1 : shk_mad64sv(e1, 1u, k);  // see shk_norm16k
+    uint64_t t2 = m == 0 ? k + (uint64_t)(int64_t)(int32_t)e2 : shk_mad64sv(e2, 1u, k);
+    t1 = shk_mad64sv((uint32_t)s1[4 * m + 1], 1u << 8, t1);
+    t2 = shk_mad64sv((uint32_t)s2[4 * m + 1], 1u << 8, t2);
+    t1 = shk_mad64sv((uint32_t)s1[4 * m + 2], 1u << 16, t1);
+    t2 = shk_mad64sv((uint32_t)s2[4 * m + 2], 1u << 16, t2);
+    t1 = shk_mad64sv((uint32_t)s1[4 * m + 3], 1u << 24, t1);
+    t2 = shk_mad64sv((uint32_t)s2[4 * m + 3], 1u << 24, t2);
     o1[m] = (uint32_t)t1;
     o2[m] = (uint32_t)t2;
     c1 = (uint32_t)(t1 >> 32);
@@ -70,42 +107,11 @@ __device__ __forceinline__ void shk_norm16x2(const shk_v16i& s1, const shk_v16i&
   o1[4] = c1;
   o2[4] = c2;
 }
-// 16 non-negative partial sums (< 2^22) at byte spacing -> 4 limbs + carry (< 2^15)
-__device__ __forceinline__ void shk_norm16(const shk_v16i& s, uint32_t out[5]) {
-  uint32_t cin = 0;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const uint32_t e = (uint32_t)s[4 * m] + cin;
-    uint64_t t = shk_mad64((uint32_t)s[4 * m + 1], 1u << 8, (uint64_t)e);
-    t = shk_mad64((uint32_t)s[4 * m + 2], 1u << 16, t);
-    t = shk_mad64((uint32_t)s[4 * m + 3], 1u << 24, t);
-    out[m] = (uint32_t)t;
-    cin = (uint32_t)(t >> 32);
-  }
-  out[4] = cin;
-}
-// accumulator start values of this lane: O_(16 h + r), r < 16  (delta = -(2^20 * (2^256 - 1) / 255) mod p, little-endian
-// bytes 17, 16, 240, 239, 160, 232, 217, then 239 for the remaining 25)
-__device__ __forceinline__ shk_v16i shk_mfma_cinit(uint32_t lane) {
-  const int K = 1 << 20;
-  const bool up = lane >= 32;
-  shk_v16i c;
-  c[0] = K + (up ? 239 : 17);
-  c[1] = K + (up ? 239 : 16);
-  c[2] = K + (up ? 239 : 240);
-  c[3] = K + 239;
-  c[4] = K + (up ? 239 : 160);
-  c[5] = K + (up ? 239 : 232);
-  c[6] = K + (up ? 239 : 217);
-#pragma unroll
-  for (int r = 7; r < 16; ++r) c[r] = K + 239;
-  return c;
-}
 
 // d = (a - b) * w.  MFMA group 1 (the elements of lanes 0..31) uses the matrices (w1, nw1), group 2 (lanes 32..63)
 // uses (w2, nw2); all 64 lanes pass their own 16-byte fragment of both.  Every lane of the wave must be active.
 __device__ __forceinline__ fp shk_mfma_submul2(const fp& a, const fp& b, const shk_v4i w1, const shk_v4i nw1, const shk_v4i w2,
-                                               const shk_v4i nw2, const shk_v16i& cinit) {
+                                               const shk_v4i nw2, const shk_kinit& kc) {
   uint32_t A[8], B[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -119,12 +125,13 @@ __device__ __forceinline__ fp shk_mfma_submul2(const fp& a, const fp& b, const s
   }
   const shk_v4i a1 = {(int)A[0], (int)A[1], (int)A[2], (int)A[3]}, a2 = {(int)A[4], (int)A[5], (int)A[6], (int)A[7]};
   const shk_v4i b1 = {(int)B[0], (int)B[1], (int)B[2], (int)B[3]}, b2 = {(int)B[4], (int)B[5], (int)B[6], (int)B[7]};
-  shk_v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, a1, cinit, 0, 0, 0);
-  shk_v16i acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, a2, cinit, 0, 0, 0);
+  const shk_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  shk_v16i acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w1, a1, zero, 0, 0, 0);
+  shk_v16i acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(w2, a2, zero, 0, 0, 0);
   acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(nw1, b1, acc1, 0, 0, 0);
   acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(nw2, b2, acc2, 0, 0, 0);
   uint32_t r1[5], r2[5];
-  shk_norm16x2(acc1, acc2, r1, r2);
+  shk_norm16x2k(acc1, acc2, kc, r1, r2);
 #pragma unroll
   for (int i = 0; i < 5; ++i) shk_swap32(r1[i], r2[i]);
   // r1 = limbs 0..3 + carry into limb 4, r2 = limbs 4..7 + carry out (weight 2^256), all of this lane's own element
@@ -150,8 +157,8 @@ __device__ __forceinline__ fp shk_mfma_submul2(const fp& a, const fp& b, const s
   }
   return r;
 }
-__device__ __forceinline__ fp shk_mfma_submul(const fp& a, const fp& b, const shk_v4i w, const shk_v4i nw, const shk_v16i& cinit) {
-  return shk_mfma_submul2(a, b, w, nw, w, nw, cinit);
+__device__ __forceinline__ fp shk_mfma_submul(const fp& a, const fp& b, const shk_v4i w, const shk_v4i nw, const shk_kinit& kc) {
+  return shk_mfma_submul2(a, b, w, nw, w, nw, kc);
 }
 __device__ __forceinline__ shk_v4i shk_ld_frag(const uint32_t (*rows)[4], uint32_t lane) {
   const uint4 q = *reinterpret_cast<const uint4*>(rows[lane]);

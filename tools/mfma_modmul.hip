@@ -23,6 +23,7 @@
 #include <string.h>
 #include <vector>
 #include "fp256.cuh"
+#include "mfma_split.cuh"
 
 #define CK(x)                                                                                \
   do {                                                                                       \
@@ -126,6 +127,55 @@ __global__ void __launch_bounds__(64) k_check(const fp* a, const fp* b, const Fr
     fp_store(out + base + l, fp_canon(mfma_submul(x, y, wf, nwf, ci)));
     fp_store(ref + base + l, fp_canon(fp_mul(fp_sub(x, y), w)));
   }
+}
+
+// ---- split form (mfma_split.cuh): lane c holds limbs 0..3, lane c + 32 limbs 4..7 of element c ---------------------------
+__device__ __forceinline__ hf hf_load(const fp* p, bool hb) {
+  const uint4 q = reinterpret_cast<const uint4*>(p)[hb ? 1 : 0];
+  hf r;
+  r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+  return r;
+}
+__device__ __forceinline__ void hf_store(fp* p, const hf& r, bool hb) {
+  reinterpret_cast<uint4*>(p)[hb ? 1 : 0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+}
+// out[3n .. 3n+2] = a + b, a - b, (a - b) w in split arithmetic (lazily reduced; the host canonicalises)
+__global__ void __launch_bounds__(64) k_check_split(const fp* a, const fp* b, const Frags* f, fp* out, int n) {
+  const int l = threadIdx.x, c = l & 31;
+  const bool hb = l >= 32;
+  const v4i wf = f->w[l], nwf = f->nw[l];
+  const shk_kinit ci = shk_mfma_kinit(l);
+  for (int base = blockIdx.x * 32; base < n; base += gridDim.x * 32) {
+    const hf x = hf_load(a + base + c, hb), y = hf_load(b + base + c, hb);
+    hf_store(out + 3 * (size_t)(base + c), hf_add(x, y, hb), hb);
+    hf_store(out + 3 * (size_t)(base + c) + 1, hf_sub(x, y, hb), hb);
+    hf_store(out + 3 * (size_t)(base + c) + 2, hf_submul(x, y, wf, nwf, ci, hb), hb);
+  }
+}
+// split <-> whole round trip: out[n] = the element as the lower / upper lane sees it after hf_to_whole(A = a, B = b)
+__global__ void __launch_bounds__(64) k_check_convert(const fp* a, const fp* b, fp* out, int n) {
+  const int l = threadIdx.x, c = l & 31;
+  const bool hb = l >= 32;
+  for (int base = blockIdx.x * 32; base < n; base += gridDim.x * 32) {
+    const hf x = hf_load(a + base + c, hb), y = hf_load(b + base + c, hb);
+    const fp w = hf_to_whole(x, y);  // lower lane: a whole, upper lane: b whole
+    fp_store(out + 2 * (size_t)(base + c) + (hb ? 1 : 0), w);
+  }
+}
+__global__ void __launch_bounds__(256) k_bfly_split(const fp* in, const Frags* f, fp* out) {
+  const int l = threadIdx.x & 63, g = blockIdx.x * 256 + threadIdx.x;
+  const bool hb = l >= 32;
+  const v4i wf = f->w[l], nwf = f->nw[l];
+  const shk_kinit ci = shk_mfma_kinit(l);
+  hf x = hf_load(in + (g >> 1), hb), y = hf_load(in + (g >> 1) + 1, hb);
+#pragma unroll 1
+  for (int i = 0; i < 512; ++i) {
+    const hf s = hf_add(x, y, hb);
+    const hf d = hf_submul(x, y, wf, nwf, ci, hb);
+    x = s;
+    y = d;
+  }
+  hf_store(out + (g >> 1), hf_add(x, y, hb), hb);
 }
 
 constexpr int ITERS = 512;
@@ -371,6 +421,55 @@ int main() {
   printf("check: %ld (a, b, w) triples, %ld mismatches against fp_mul(fp_sub(a, b), w)\n", total, bad);
   if (bad) return 1;
 
+  // ---- split form: a + b, a - b, (a - b) w against the whole-form functions, and the split <-> whole conversion -----------
+  {
+    // rare paths: carries that ripple through a whole half and across the top
+    fp ones;
+    for (int k = 0; k < 8; ++k) ones.v[k] = 0xffffffffu;
+    fp lowones = fp_zero();
+    for (int k = 0; k < 4; ++k) lowones.v[k] = 0xffffffffu;
+    ha[ix] = ones; hb[ix] = fp_one(); ++ix;
+    ha[ix] = lowones; hb[ix] = fp_one(); ++ix;
+    ha[ix] = fp_zero(); hb[ix] = fp_one(); ++ix;          // 0 - 1: borrows through everything
+    ha[ix] = fp_one(); hb[ix] = ones; ++ix;
+    { fp t = fp_zero(); t.v[4] = 1; ha[ix] = t; hb[ix] = fp_one(); ++ix; }   // 2^128 - 1: borrow stops at limb 4
+    { fp t = ones; t.v[0] = 0xfffffea0u; ha[ix] = t; hb[ix] = t; ++ix; }
+    CK(hipMemcpy(da, ha.data(), N * sizeof(fp), hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), N * sizeof(fp), hipMemcpyHostToDevice));
+    fp* d3;
+    CK(hipMalloc(&d3, (size_t)3 * N * sizeof(fp)));
+    std::vector<fp> o3((size_t)3 * N);
+    long sbad = 0, stot = 0;
+    for (size_t wi = 0; wi < ws.size(); wi += 5) {
+      const fp w = ws[wi];
+      build_frags(w, &hf);
+      CK(hipMemcpy(df, &hf, sizeof hf, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(k_check_split, dim3(1024), dim3(64), 0, 0, da, db, df, d3, N);
+      CK(hipGetLastError());
+      CK(hipMemcpy(o3.data(), d3, (size_t)3 * N * sizeof(fp), hipMemcpyDeviceToHost));
+      for (int i = 0; i < N; ++i) {
+        const fp want[3] = {fp_canon(fp_add(ha[i], hb[i])), fp_canon(fp_sub(ha[i], hb[i])), fp_canon(fp_mul(fp_sub(ha[i], hb[i]), w))};
+        for (int k = 0; k < 3; ++k) {
+          ++stot;
+          const fp got = fp_canon(o3[(size_t)3 * i + k]);
+          if (memcmp(&got, &want[k], sizeof(fp))) {
+            if (sbad < 5) printf("SPLIT MISMATCH i=%d op=%d\n", i, k);
+            ++sbad;
+          }
+        }
+      }
+    }
+    hipLaunchKernelGGL(k_check_convert, dim3(1024), dim3(64), 0, 0, da, db, d3, N);
+    CK(hipMemcpy(o3.data(), d3, (size_t)2 * N * sizeof(fp), hipMemcpyDeviceToHost));
+    long cbad = 0;
+    for (int i = 0; i < N; ++i)
+      if (memcmp(&o3[(size_t)2 * i], &ha[i], sizeof(fp)) || memcmp(&o3[(size_t)2 * i + 1], &hb[i], sizeof(fp))) ++cbad;
+    printf("split form: %ld results (a + b, a - b, (a - b) w), %ld mismatches; split <-> whole: %ld mismatches of %d\n", stot, sbad,
+           cbad, N);
+    if (sbad || cbad) return 1;
+    CK(hipFree(d3));
+  }
+
   // throughput
   const int blocks = 256 * 8;
   const double ops = (double)blocks * 256 * ITERS;
@@ -386,5 +485,7 @@ int main() {
   printf("butterfly VALU:                   %8.3f ms  %7.2f G/s\n", t, ops / t / 1e6);
   t = time_kernel([&] { hipLaunchKernelGGL(k_bfly_mfma, dim3(blocks), dim3(256), 0, 0, da, df, dout); });
   printf("butterfly MFMA i8 shared twiddle: %8.3f ms  %7.2f G/s\n", t, ops / t / 1e6);
+  t = time_kernel([&] { hipLaunchKernelGGL(k_bfly_split, dim3(blocks), dim3(256), 0, 0, da, df, dout); });
+  printf("butterfly MFMA, split form:       %8.3f ms  %7.2f G/s  (32 butterflies per wave instruction group)\n", t, ops / 2 / t / 1e6);
   return 0;
 }
