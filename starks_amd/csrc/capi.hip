@@ -324,9 +324,37 @@ int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp
 
 void choose_radices(int log_n, std::vector<int>* out) {
   out->clear();
+  // experiments: STARKHIP_NTT_RADICES="10,10" (digits 2..11, at most 4 passes) applies to the sizes it sums to
+  if (const char* e = getenv("STARKHIP_NTT_RADICES")) {
+    std::vector<int> r;
+    int sum = 0;
+    bool ok = true;
+    for (const char* p = e; *p && ok;) {
+      char* end = nullptr;
+      const long v = strtol(p, &end, 10);
+      if (end == p || v < 2 || v > 11) ok = false;
+      r.push_back((int)v);
+      sum += (int)v;
+      p = (*end == ',') ? end + 1 : end;
+      if (*end && *end != ',') ok = false;
+    }
+    if (ok && sum == log_n && r.size() >= 1 && r.size() <= 4) {
+      *out = r;
+      return;
+    }
+  }
   if (log_n <= 8) {
     out->push_back(log_n);
     return;
+  }
+  // Two passes of radix 2^9 / 2^10 (2048-element tiles) where they were measured ahead of three passes of 1024-element
+  // tiles (one inter-pass twiddle modmul and one read + write of the vector fewer per transform; 2^18
+  // and everything from 2^21 up measured level or behind).  The matrix-core passes have no such radices: under
+  // STARKHIP_NTT_PATH=mfma the three-pass decomposition stays.
+  if (!use_mfma_path()) {
+    if (log_n == 17) { *out = {9, 8}; return; }
+    if (log_n == 19) { *out = {9, 10}; return; }
+    if (log_n == 20) { *out = {10, 10}; return; }
   }
   const int m = (log_n + 7) / 8, base = log_n / m, rem = log_n % m;
   for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));

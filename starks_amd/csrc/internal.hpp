@@ -27,6 +27,8 @@ struct NttPassArgs {
   uint32_t debug;     // diagnostic (SHK_STAMPS) builds only: 1 = this pass records its phase stamps
   const fp* tw2;      // MFMA column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k); else null
   const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null
+  uint32_t xcd_per;   // 0: tile = blockIdx.x.  Else workgroups are dealt to the 8 XCDs round-robin and tile = (blockIdx.x & 7) *
+                      // xcd_per + (blockIdx.x >> 3): adjacent tiles run on the SAME XCD (they share 128-byte lines when T < 4)
 };
 
 // ---- ntt.hip ----------------------------------------------------------------------------------

@@ -182,17 +182,24 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 #endif
 template <int LOG_R, int LOG_T, bool LAST>
 __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) ntt_pass_kernel(NttPassArgs a) {
-  static_assert(LOG_R >= 2 && LOG_R <= 8 && LOG_R + LOG_T >= 8, "unsupported tile");
+  static_assert(LOG_R >= 2 && LOG_R <= 11 && LOG_T >= 0 && LOG_R + LOG_T >= 8 && LOG_R + LOG_T <= 12, "unsupported tile");
   constexpr int G = (LOG_R + 1) / 2;  // register groups (two levels each, the last may have one)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
   const uint32_t tid = threadIdx.x;
-  const uint64_t tile0 = (uint64_t)blockIdx.x << LOG_T;
+  uint64_t tile = blockIdx.x;
+  if (a.xcd_per) {
+    tile = (uint64_t)(blockIdx.x & 7u) * a.xcd_per + (blockIdx.x >> 3);
+    if ((tile << LOG_T) >= a.total) return;  // grid padding (whole workgroup, before any barrier)
+  }
+  const uint64_t tile0 = tile << LOG_T;
   TileThread th;
   th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0; th.sbase = 0;
   ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
   if constexpr (G > 1) ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
   if constexpr (G > 2) ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
   if constexpr (G > 3) ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0);
+  if constexpr (G > 4) ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0);
+  if constexpr (G > 5) ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0);
 
   // ---- store: position i of the DIF output holds frequency k = bitrev(i) ----------------------------
   if (!th.active) return;

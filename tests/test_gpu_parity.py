@@ -982,6 +982,25 @@ def test_mfma_tile_passes_parity(sa, tmp_path):
     assert " passed" in out.stdout
 
 
+@pytest.mark.parametrize("env", [
+    {"STARKHIP_NTT_RADICES": "7,7,6", "STARKHIP_XCD_SWZ": "2"},      # the three-pass plan for 2^20, every tile pass XCD-mapped
+    {"STARKHIP_NTT_RADICES": "10,10", "STARKHIP_TILE_LOG_BIG": "12", "STARKHIP_XCD_SWZ": "0"},  # 4096-element tiles
+    {"STARKHIP_NTT_RADICES": "11,9", "STARKHIP_TILE_LOG_BIG": "11"},  # radix 2^11: one column / one row per tile
+    {"STARKHIP_NTT_RADICES": "6,6,4", "STARKHIP_TILE_LOG": "11"},     # 2^16 in three passes, 2048-element tiles
+], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048"])
+def test_alternate_ntt_plans_parity(sa, env):
+    """Every decomposition the plan / tile knobs can select gives the same bytes: the NTT golden vectors (reference digests to
+    2^20), every size against the oracle and the 2^22 / 2^24 digests, in a child process with the knobs set."""
+    import subprocess, sys
+    from conftest import ROOT
+    sel = "test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
+                          "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, **env), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
 def test_pinned_host_buffers_skip_staging(sa):
     """sh_host_alloc buffers go through the host-buffer entry points without the staging copy and give the same bytes."""
     n = 1 << 14
