@@ -168,7 +168,8 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 
   // ---- hand the elements to the next group through LDS ---------------------------------------------
   if (g < G - 1) {
-    if (g > 0) __syncthreads();  // everyone has finished reading the previous image
+    // in place: for g > 0 these are exactly the slots this thread read at the top of the group (element (i, t) always lives
+    // at the same slot), and no other thread touches them before the barrier below -- one barrier per exchange
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       lds_put_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)), th.x[h]);

@@ -1,20 +1,8 @@
-# experiment: two-pass NTT plans (STARKHIP_NTT_RADICES / STARKHIP_TILE_LOG_BIG / STARKHIP_XCD_SWZ) -- forward+inverse timing
 set -e
-run() {  # radices logn batches...
-  local rad=$1 logn=$2; shift 2
-  echo "== radices $rad"
-  STARKHIP_XCD_SWZ=1 STARKHIP_NTT_RADICES=$rad timeout -k 10 120 python tools/ntt_batch_time.py $logn "$@"
-}
-run 6,6,5 17 1 64 256
-run 8,9 17 1 64 256
-run 9,8 17 1 64 256
-run 6,6,6 18 1 32 128
-run 9,9 18 1 32 128
-run 7,6,6 19 1 16 64
-run 9,10 19 1 16 64
-run 10,9 19 1 16 64
-run 7,7,6 20 1 8 32
-run 10,10 20 1 8 32
-run 7,7,7 21 1 4 16
-run 10,11 21 1 4 16
-run 11,10 21 1 4 16
+SEL="test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or test_fri_proofs_golden"
+timeout -k 10 300 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "$SEL" -p no:cacheprovider > gpurun_out/plan_par.txt 2>&1 || { tail -30 gpurun_out/plan_par.txt; echo "PARITY FAILED"; exit 1; }
+tail -1 gpurun_out/plan_par.txt
+timeout -k 10 120 python tools/ntt_batch_time.py 20 1 8 32
+timeout -k 10 120 python tools/ntt_batch_time.py 19 64
+timeout -k 10 120 python tools/ntt_batch_time.py 24 1
+timeout -k 10 120 python tools/ntt_batch_time.py 16 64
