@@ -29,6 +29,9 @@ struct NttPassArgs {
   const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null
   uint32_t xcd_per;   // 0: tile = blockIdx.x.  Else workgroups are dealt to the 8 XCDs round-robin and tile = (blockIdx.x & 7) *
                       // xcd_per + (blockIdx.x >> 3): adjacent tiles run on the SAME XCD (they share 128-byte lines when T < 4)
+  uint32_t sharers;   // column passes with xcd_per: the number of (vector, prefix block) pairs = total >> log_S, all of which
+                      // read the same tw2 rows; tiles are then enumerated sharer-fastest, so that the tiles that share a row
+                      // set run back to back behind one L2 (0: plain order)
 };
 
 // ---- ntt.hip ----------------------------------------------------------------------------------

@@ -10,13 +10,14 @@ namespace {
 // Tiles narrower than 128 bytes (T < 4: the big-radix passes) share their cache lines with the neighbouring tile; workgroups
 // are dealt to the 8 XCDs round-robin, so neighbours would sit behind different L2s and every line would be fetched (or
 // written back partially) twice.  Default (1): such launches map adjacent tiles to the same XCD (measured on the T = 1
-// variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ: 0 = never, 2 = every tile pass (measured level for T >= 4).
+// variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ: 0 = never, 2 = every tile pass (measured level for T >= 4),
+// 3 = as 1 plus the sharer-fastest order below.
 int xcd_swizzle() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_XCD_SWZ");
     v = e ? atoi(e) : 1;
-    if (v < 0 || v > 2) v = 0;
+    if (v < 0 || v > 3) v = 0;
   }
   return v;
 }
@@ -44,8 +45,16 @@ hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
   if (tiles > 0x7ffffff0ull) return hipErrorInvalidValue;
   NttPassArgs b = a;
   uint64_t grid = tiles;
-  if (xcd_swizzle() && (xcd_swizzle() == 2 || LOG_T < 2) && tiles >= 64) {
+  // column passes whose twiddle rows (tw2) are shared by several vectors / prefix blocks: sharer-fastest order, XCD-local.
+  // Opt-in only (STARKHIP_XCD_SWZ=3): it removes the per-vector re-fetch of the rows (2 * FETCH_SIZE of the 2^20 x 8 column
+  // pass 540 -> 325 MB) but measured 3-8 % SLOWER -- the sharers sit 2^k bytes apart, so the concurrently running tiles
+  // all map to the same memory channels.
+  const uint64_t sharers = LAST ? 0 : (a.total >> a.log_S);
+  const bool share = !LAST && a.tw2 && sharers >= 2 && sharers <= 0xffffffffull && a.log_S >= (uint32_t)LOG_T + 2 &&
+                     tiles <= 0xffffffffull && xcd_swizzle() == 3;
+  if (xcd_swizzle() && (xcd_swizzle() == 2 || LOG_T < 2 || share) && tiles >= 64) {
     b.xcd_per = (uint32_t)((tiles + 7) / 8);
+    b.sharers = share ? (uint32_t)sharers : 0;
     grid = 8ull * b.xcd_per;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), LDS, st, b);

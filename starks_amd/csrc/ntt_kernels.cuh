@@ -191,6 +191,15 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
   if (a.xcd_per) {
     tile = (uint64_t)(blockIdx.x & 7u) * a.xcd_per + (blockIdx.x >> 3);
     if ((tile << LOG_T) >= a.total) return;  // grid padding (whole workgroup, before any barrier)
+    if (!LAST && a.sharers) {
+      // order: (line group of adjacent column tiles, sharer, tile inside the line group) -- the tiles that share 128-byte
+      // lines (T < 4) stay adjacent, then come the other sharers of the same twiddle rows
+      constexpr int GRP = LOG_T < 2 ? 2 - LOG_T : 0;
+      const uint32_t tl = (uint32_t)tile;
+      const uint32_t low = tl & ((1u << GRP) - 1u), rest = tl >> GRP;
+      const uint32_t hi = rest / a.sharers, v = rest - hi * a.sharers;
+      tile = ((uint64_t)v << (a.log_S - LOG_T)) + ((hi << GRP) | low);
+    }
   }
   const uint64_t tile0 = tile << LOG_T;
   TileThread th;

@@ -987,13 +987,15 @@ def test_mfma_tile_passes_parity(sa, tmp_path):
     {"STARKHIP_NTT_RADICES": "10,10", "STARKHIP_TILE_LOG_BIG": "12", "STARKHIP_XCD_SWZ": "0"},  # 4096-element tiles
     {"STARKHIP_NTT_RADICES": "11,9", "STARKHIP_TILE_LOG_BIG": "11"},  # radix 2^11: one column / one row per tile
     {"STARKHIP_NTT_RADICES": "6,6,4", "STARKHIP_TILE_LOG": "11"},     # 2^16 in three passes, 2048-element tiles
-], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048"])
+    {"STARKHIP_XCD_SWZ": "3"},                                        # column tiles in sharer-fastest order
+], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "sharer_order"])
 def test_alternate_ntt_plans_parity(sa, env):
     """Every decomposition the plan / tile knobs can select gives the same bytes: the NTT golden vectors (reference digests to
     2^20), every size against the oracle and the 2^22 / 2^24 digests, in a child process with the knobs set."""
     import subprocess, sys
     from conftest import ROOT
-    sel = "test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden"
+    sel = ("test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or "
+           "test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or test_stark_batch_units_and_device_api")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
                           "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, **env), cwd=ROOT)
