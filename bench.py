@@ -638,6 +638,39 @@ def main():
                                        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")), 50)
         line["single_vector_elements_per_s"] = 2 * n / single_ms * 1e3
         line["single_vector_ms_per_fwd_inv"] = round(single_ms, 5)
+        if B >= 2 and B % 2 == 0:
+            # The same step with its vectors split over TWO contexts (= two streams), free-running: the launches of one
+            # stream fill the ramps and tails of the other's.  Reported beside `value`, never as `value`: with two kernels
+            # resident at once a per-launch duration no longer maps to a per-launch byte count.
+            other = ctypes.c_void_p()
+            dev.ck(L.sh_ctx_create(dev_index, ctypes.byref(other)), "sh_ctx_create")
+            half = B // 2
+            dx2 = ctypes.c_void_p(dx.value + 32 * n * half)
+            dy2 = ctypes.c_void_p(dy.value + 32 * n * half)
+
+            def step2():
+                dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, half, w, 0), "ntt")
+                dev.ck(L.sh_dev_ntt(other, dx2, dy2, n, half, w, 0), "ntt")
+                dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, half, w, 1), "intt")
+                dev.ck(L.sh_dev_ntt(other, dy2, dy2, n, half, w, 1), "intt")
+
+            def sync2():
+                dev.sync()
+                dev.ck(L.sh_sync(other), "sh_sync")
+
+            for _ in range(3):
+                step2()
+            sync2()
+            t2 = time.perf_counter()
+            for _ in range(30):
+                step2()
+            sync2()
+            ms2 = (time.perf_counter() - t2) * 1e3 / 30
+            dev.ck(L.sh_dev_to_wire(ctx, dy, b, n * B), "dl")  # canonical wire form of both; a = the input (above)
+            ok2 = a.raw == b.raw
+            line["two_stream_elements_per_s"] = 2 * n * B / ms2 * 1e3
+            line["two_stream_check"] = {"roundtrip_ok": ok2, "ms_per_step": round(ms2, 5)}
+            L.sh_ctx_destroy(other)
     dev.free(dx)
     dev.free(dy)
     if not args.no_c5:
