@@ -20,7 +20,7 @@ if __name__ == "__main__":
     F, W, D = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE"), durations(sdir)
     res = {"workload": "bench.py --logn %d --batch %d: 2^%d-point NTT + inverse NTT, %d vectors per step" % (logn, vectors, logn, vectors),
            "logn": logn, "vectors_per_step": vectors, "unit": "bytes per launch",
-           "algorithmic_bytes_per_launch": 64.0 * (1 << logn) * vectors / 3,
+           "algorithmic_bytes_per_launch": None,  # 64 B per element per transform / passes, filled in below
            "correction": "2*FETCH_SIZE + WRITE_SIZE, counters in KiB (gfx950: FETCH_SIZE = 1/2 of a wide coalesced stream)",
            "kernels": {}}
     tot_b = tot_n = 0
@@ -35,5 +35,11 @@ if __name__ == "__main__":
         tot_b += (fb + wb) * len(F[k])
         tot_n += len(F[k])
     res["ntt_pass_kernel_mean_hbm_bytes_per_launch"] = tot_b / tot_n
+    # launches per transform: the row pass (LAST = true) runs once per transform
+    last = sum(v["launches"] for k, v in res["kernels"].items() if "true>" in k)
+    res["passes_per_transform"] = round(tot_n / last) if last else None
+    if last:
+        res["algorithmic_bytes_per_launch"] = 64.0 * (1 << logn) * vectors / res["passes_per_transform"]
+        res["traffic_over_algorithmic"] = res["ntt_pass_kernel_mean_hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
