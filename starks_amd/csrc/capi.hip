@@ -79,7 +79,7 @@ struct NttPlan {
   bool scaled = false;       // multiply by n^-1 (inverse transform)
   fp root;                   // effective root (already inverted for inverse transforms)
   std::vector<int> radix;    // log2 radix of each pass
-  std::vector<fp*> wR;       // per pass: powers of root^(n/R), R/2 entries
+  std::vector<const fp2*> wR;  // per pass: powers of root^(n/R), R/2 entries, as (w, w 2^128) pairs
   std::vector<fp*> tw2;      // per column pass: [k][j2] copy of tw for the MFMA tile pass (null when it is not used)
   std::vector<void*> mats;   // per pass: the same powers as MFMA operand images (TwMat[R/2]), null for radix < 2^5
   std::vector<PowTable> tw;  // per column pass d: table of root^(P_d) (times n^-1 on pass 0 when scaled)
@@ -427,7 +427,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
   if (scaled) ninv = h_pow(h_inv(fp_from_u32(2u)), (uint64_t)pl->log_n);  // n^-1 = (2^-1)^log_n
   int rc = build_pow_table(c, pl, root_eff, pl->log_n, nullptr, &pl->base);
   if (rc == SH_OK && pl->log_n >= 2) {
-    std::map<int, fp*> wr_by_radix;
+    std::map<int, const fp2*> wr_by_radix;
     std::map<int, void*> mats_by_radix;
     int log_P = 0;
     for (size_t d = 0; d < m && rc == SH_OK; ++d) {
@@ -437,9 +437,17 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
         std::vector<fp> t((size_t)1 << (r - 1));
         t[0] = fp_one();
         for (size_t i = 1; i < t.size(); ++i) t[i] = fp_mul(t[i - 1], wr);
+        // the butterflies multiply by these through fp_mul2: every entry is followed by its image times 2^128
+        fp two128 = fp_zero();
+        two128.v[4] = 1;
+        std::vector<fp> pairs(2 * t.size());
+        for (size_t i = 0; i < t.size(); ++i) {
+          pairs[2 * i] = t[i];
+          pairs[2 * i + 1] = fp_canon(fp_mul(t[i], two128));
+        }
         fp* dev = nullptr;
-        rc = upload_table(c, pl, t, &dev);
-        wr_by_radix[r] = dev;
+        rc = upload_table(c, pl, pairs, &dev);
+        wr_by_radix[r] = reinterpret_cast<const fp2*>(dev);
         mats_by_radix[r] = nullptr;
         if (rc == SH_OK && r >= 5 && r <= 8) {  // operand images for the matrix-core butterflies (ntt_mfma.hip)
           std::vector<TwMat> mm(t.size());

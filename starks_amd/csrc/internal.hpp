@@ -12,7 +12,7 @@ struct NttPassArgs {
   uint32_t log_n;     // log2 of the transform length
   uint32_t log_S;     // column pass: log2 stride between successive points of a column
   uint32_t log_P;     // row pass: log2 number of rows per transform (n / R)
-  const fp* wR;       // w^(n/R * k), k < R/2
+  const fp2* wR;      // w^(n/R * k), k < R/2, each with its second image w * 2^128 mod p (fp256.cuh: fp_mul2)
   // column pass: table of g = w^P, order R*S:  g^e = lo[e & mask] (* hi[e >> lb] unless direct)
   const fp* tw_lo;
   const fp* tw_hi;

@@ -155,10 +155,10 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
         if (q == 0) {
           // twiddle 1
         } else if (q == 1 && beta == 0) {
-          if (hl & 1) d = fp_mul(d, fp_load(a.wR + (R / 4)));  // w^(R/4), the 4th root of unity
+          if (hl & 1) d = fp_mul2(d, fp2_load(a.wR + (R / 4)));  // w^(R/4), the 4th root of unity
         } else {
           const uint32_t ex = (il & ((1u << q) - 1u)) << (LOG_R - 1 - q);
-          d = fp_mul(d, fp_load(a.wR + ex));
+          d = fp_mul2(d, fp2_load(a.wR + ex));
         }
         th.x[hl] = s;
         th.x[hh] = d;

@@ -182,6 +182,19 @@ def test_reference_fft_unit_tests_on_other_fields():
     assert [int(v) for v in fft_1d(F, [0, 1, 2, 3], 31, w)] == g["fwd"]
 
 
+def test_pair_constant_product_on_the_host(tmp_path):
+    """fp_mul2 (csrc/fp256.cuh: the product by a table constant kept as the pair (w, w 2^128 mod p), what every NTT
+    butterfly uses) against fp_mul through the portable C paths of the same header: 400 k random and edge operands, canonical
+    and lazily reduced second images.  The device's inline-asm path is pinned by the GPU parity tests and tools/mul2_bench."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "native", "mul2_host.cpp")
+    exe = tmp_path / "mul2_host"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-std=c++17", "-I",
+                           os.path.join(ROOT, "starks_amd", "csrc"), src, "-o", str(exe)], stderr=subprocess.DEVNULL)
+    out = subprocess.check_output([str(exe)]).decode()
+    assert "400000 products, 0 mismatches" in out
+
+
 def test_twiddle_matrix_images(tmp_path):
     """The MFMA operand images of the matrix-core NTT passes (csrc/mfma_tw.cuh:shk_build_twmat, host code): for every
     byte k of the multiplicand, the 32 signed digits stored for it sum to w * 256^k (and to -w * 256^k) modulo p, every

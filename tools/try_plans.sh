@@ -1,6 +1,5 @@
 set -e
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-SEL="test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or test_randomized_ntt_differential or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or test_fri_proofs_golden or test_stark_proofs_golden or test_device_resident_pipeline or test_stark_batch_units_and_device_api"
+SEL="test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or test_randomized_ntt_differential or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or test_fri_proofs_golden or test_stark_proofs_golden or test_device_resident_pipeline or test_rare_carry_branches"
 timeout -k 10 400 python -m pytest tests/test_gpu_parity.py -q -x -m gpu -k "$SEL" -p no:cacheprovider > gpurun_out/plan_par.txt 2>&1 || { tail -30 gpurun_out/plan_par.txt; echo "PARITY FAILED"; exit 1; }
 tail -1 gpurun_out/plan_par.txt
 timeout -k 10 120 python tools/ntt_batch_time.py 20 1 8 32
@@ -8,9 +7,4 @@ timeout -k 10 120 python tools/ntt_batch_time.py 19 64
 timeout -k 10 120 python tools/ntt_batch_time.py 24 1
 timeout -k 10 120 python tools/ntt_batch_time.py 22 4
 timeout -k 10 120 python tools/ntt_batch_time.py 16 64
-B="python3 bench.py --no-extras --no-cpu-baseline --no-c5 --no-single --logn 20 --batch 8 --steps 20 --warmup 3"
-rm -rf gpurun_out/sf_f gpurun_out/sf_w
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/sf_f --pmc FETCH_SIZE -- $B > gpurun_out/sf_f.log 2>&1
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/sf_w --pmc WRITE_SIZE -- $B > gpurun_out/sf_w.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/sf_f gpurun_out/sf_w
 python3 bench.py --workload c5 --no-cpu-baseline | python3 -c "import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5', l['value'])"
