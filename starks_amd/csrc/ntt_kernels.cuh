@@ -14,6 +14,8 @@
 // w^(n/R) shared by every pass that uses radix R; the bit-reversed order DIF leaves is undone by the
 // store addresses.  The last two levels of each tile transform have twiddles 1 / w^(R/4) only.
 #pragma once
+#include <type_traits>
+
 #include "internal.hpp"
 
 
@@ -57,6 +59,14 @@ __device__ __forceinline__ fp tw_lookup(const NttPassArgs& a, uint64_t e) {
   return fp_mul(lo, hi);
 }
 
+template <class F>
+__device__ __forceinline__ void static_for4(F&& f) {
+  f(std::integral_constant<int, 0>{});
+  f(std::integral_constant<int, 1>{});
+  f(std::integral_constant<int, 2>{});
+  f(std::integral_constant<int, 3>{});
+}
+
 // Per-thread state carried across the register groups of one tile pass.
 struct TileThread {
   fp x[4];
@@ -89,9 +99,12 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 
   if (g == 0 || (LAST && g == 1)) {
     // (re)derive the global coordinates of this thread's column/row: t changes between the
-    // rfast mapping of the row pass's first group and the t-fast mapping of the later ones
-    const uint64_t col = tile0 + th.t;
-    th.active = col < a.total;
+    // rfast mapping of the row pass's first group and the t-fast mapping of the later ones.
+    // Threads past the end (partial last tile) work on a copy of the last valid column / row and store nothing: every
+    // load is unconditional and in bounds, so the four loads of a thread are requested back to back.
+    const uint64_t col_raw = tile0 + th.t;
+    th.active = col_raw < a.total;
+    const uint64_t col = th.active ? col_raw : a.total - 1;
     if (LAST) {
       const uint64_t b = col >> a.log_P;
       const uint32_t pp = (uint32_t)(col & ((1ull << a.log_P) - 1));
@@ -116,55 +129,81 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     } else {
       th.j2 = col & ((1ull << a.log_S) - 1);
       th.gbase = ((col >> a.log_S) << (LOG_R + a.log_S)) + th.j2;
-      th.sbase = (col >> a.log_S) * a.src_n + th.j2;  // first pass: P = 1, col >> log_S is the vector index
+      th.sbase = (col >> a.log_S) * a.src_n;  // first pass: P = 1, col >> log_S is the vector index
     }
   }
 
+  // ---- the twiddles of this group's (up to) four butterflies b = 2 lv + pr: which exist is known at compile time ---------
+  constexpr int qhi = LOG_R - 1 - 2 * g;
+  auto tw_needed = [](int b) constexpr {
+    const int q = qhi - (b >> 1), pr = b & 1;
+    if (q <= 0) return false;                        // level absent, or twiddle 1
+    const int lb = q - beta;
+    const int hl = lb == 1 ? pr : 2 * pr;
+    if (q == 1 && beta == 0) return (hl & 1) != 0;   // 1 or w^(R/4)
+    return true;
+  };
+  auto tw_load = [&](int b) {
+    const int q = qhi - (b >> 1), pr = b & 1;
+    const int lb = q - beta;
+    const int hl = lb == 1 ? pr : 2 * pr;
+    if (q == 1 && beta == 0) return fp2_load(a.wR + (R / 4));  // w^(R/4), the 4th root of unity
+    const uint32_t il = th.ibase | ((uint32_t)hl << beta);
+    const uint32_t ex = (il & ((1u << q) - 1u)) << (LOG_R - 1 - q);
+    return fp2_load(a.wR + ex);
+  };
+  // one twiddle is always in flight: the first is requested before the elements are fetched, the next before the current
+  // product (the product's inline asm keeps the compiler from moving loads across it, so source order is issue order)
+  constexpr int first_tw = tw_needed(0) ? 0 : tw_needed(1) ? 1 : tw_needed(2) ? 2 : tw_needed(3) ? 3 : 4;
+  fp2 tw_cur, tw_nxt;
+  if constexpr (first_tw < 4) tw_cur = tw_load(first_tw);
+
   // ---- fetch this group's four elements ---------------------------------------------------------
+  if (g == 0) {
+    if (a.src_n) {  // zero-padded source (first pass only): points at or beyond src_n are zero and are not read
 #pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    const uint32_t i = th.ibase | ((uint32_t)h << beta);
-    if (g == 0) {
-      if (th.active && a.src_n) {  // zero-padded source: points at or beyond src_n are zero and are not read
-        const uint64_t off = LAST ? (uint64_t)i : ((uint64_t)i << a.log_S);
-        th.x[h] = off + (LAST ? 0 : th.j2) < a.src_n ? fp_load(a.src + th.sbase + off) : fp_zero();
-      } else if (th.active) {
-        th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
-      } else {
-        th.x[h] = fp_zero();
+      for (int h = 0; h < 4; ++h) {
+        const uint32_t i = th.ibase | ((uint32_t)h << beta);
+        const uint64_t off = LAST ? (uint64_t)i : (((uint64_t)i << a.log_S) + th.j2);
+        const bool in = off < a.src_n;
+        fp v = fp_load(a.src + th.sbase + (in ? off : 0));
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v.v[w] = in ? v.v[w] : 0u;
+        th.x[h] = v;
       }
     } else {
-      th.x[h] = lds_get_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)));
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const uint32_t i = th.ibase | ((uint32_t)h << beta);
+        th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
+      }
     }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      th.x[h] = lds_get_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)));
   }
 
   // ---- butterfly levels (DIF: a' = a + b, b' = (a - b) * w^((i mod half) * 2^s)) ---------------------
-  constexpr int qhi = LOG_R - 1 - 2 * g;
-#pragma unroll
-  for (int lv = 0; lv < 2; ++lv) {
-    const int q = qhi - lv;  // global bit position of this level; half = 2^q
-    if (q >= 0) {
-      const int lb = q - beta;  // local bit
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const int hl = lb == 1 ? pr : 2 * pr;  // lower element of the pair
-        const int hh = hl | (1 << lb);
-        const uint32_t il = th.ibase | ((uint32_t)hl << beta);
-        fp s = fp_add(th.x[hl], th.x[hh]);
-        fp d = fp_sub(th.x[hl], th.x[hh]);
-        if (q == 0) {
-          // twiddle 1
-        } else if (q == 1 && beta == 0) {
-          if (hl & 1) d = fp_mul2(d, fp2_load(a.wR + (R / 4)));  // w^(R/4), the 4th root of unity
-        } else {
-          const uint32_t ex = (il & ((1u << q) - 1u)) << (LOG_R - 1 - q);
-          d = fp_mul2(d, fp2_load(a.wR + ex));
-        }
-        th.x[hl] = s;
-        th.x[hh] = d;
+  static_for4([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    constexpr int q = qhi - (b >> 1), pr = b & 1;
+    if constexpr (q >= 0) {
+      constexpr int lb = q - beta;  // local bit
+      constexpr int hl = lb == 1 ? pr : 2 * pr;  // lower element of the pair
+      constexpr int hh = hl | (1 << lb);
+      constexpr int nxt = (b < 1 && tw_needed(1)) ? 1 : (b < 2 && tw_needed(2)) ? 2 : (b < 3 && tw_needed(3)) ? 3 : 4;
+      if constexpr (tw_needed(b) && nxt < 4) tw_nxt = tw_load(nxt);
+      const fp s = fp_add(th.x[hl], th.x[hh]);
+      fp d = fp_sub(th.x[hl], th.x[hh]);
+      if constexpr (tw_needed(b)) {
+        d = fp_mul2(d, tw_cur);
+        if constexpr (nxt < 4) tw_cur = tw_nxt;
       }
+      th.x[hl] = s;
+      th.x[hh] = d;
     }
-  }
+  });
 
   // ---- hand the elements to the next group through LDS ---------------------------------------------
   if (g < G - 1) {
