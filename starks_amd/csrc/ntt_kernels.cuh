@@ -243,12 +243,46 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
   const uint64_t tile0 = tile << LOG_T;
   TileThread th;
   th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0; th.sbase = 0;
-  ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
-  if constexpr (G > 1) ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
-  if constexpr (G > 2) ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
-  if constexpr (G > 3) ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0);
-  if constexpr (G > 4) ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0);
-  if constexpr (G > 5) ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0);
+  // Column passes: the inter-pass twiddles g^(j2 k) of this thread's outputs are requested ahead of their use -- before the
+  // LAST group's butterflies (whose own twiddles are 1 and w^(R/4) only) -- so that their latency (HBM, or L2 when another
+  // vector has just read the same rows) is hidden behind arithmetic instead of being paid four times in the store loop.
+  // One is kept in flight (the first before the last group, the others one product ahead in the store loop): all four at
+  // once, or two, cost a wave per SIMD (106 / 102 VGPRs) and measured slower on single vectors and on 2^24.
+  fp itw[4];
+  auto itw_load = [&](int h) {
+    const uint32_t i = ((tid >> LOG_T) << 2) | (uint32_t)h;  // the last group's element index (beta = 0)
+    const uint32_t k = __brev(i) >> (32 - LOG_R);
+    return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
+  };
+  auto itw_request = [&]() {
+    if (!LAST && a.tw2) {
+      itw[0] = itw_load(0);
+    }
+  };
+  if constexpr (G == 1) {
+    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
+    itw_request();
+  } else {
+    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
+    if constexpr (G == 2) itw_request();
+    ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
+    if constexpr (G > 2) {
+      if constexpr (G == 3) itw_request();
+      ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
+    }
+    if constexpr (G > 3) {
+      if constexpr (G == 4) itw_request();
+      ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0);
+    }
+    if constexpr (G > 4) {
+      if constexpr (G == 5) itw_request();
+      ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0);
+    }
+    if constexpr (G > 5) {
+      if constexpr (G == 6) itw_request();
+      ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0);
+    }
+  }
 
   // ---- store: position i of the DIF output holds frequency k = bitrev(i) ----------------------------
   if (!th.active) return;
@@ -261,7 +295,8 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
       if (a.scale) v = fp_mul(v, fp_load(a.scale));
       fp_store(a.dst + th.obase + ((uint64_t)k << a.log_P), v);
     } else {
-      const fp tw = a.tw2 ? fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2) : tw_lookup(a, th.j2 * k);
+      if (a.tw2 && h + 1 < 4) itw[h + 1] = itw_load(h + 1);
+      const fp tw = a.tw2 ? itw[h] : tw_lookup(a, th.j2 * k);
       fp v = fp_mul(th.x[h], tw);
       fp_store(a.dst + th.gbase + ((uint64_t)k << a.log_S), v);
     }
