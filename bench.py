@@ -610,7 +610,7 @@ def main():
                 break
         except Exception:
             pass
-    passes = int(L.sh_ntt_passes(n))
+    passes = int(L.sh_ntt_passes(n, B))
     line = {
         "metric": "ntt_field_elements_per_sec", "value": value, "unit": "elements/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,

@@ -322,7 +322,7 @@ int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp
   return SH_OK;
 }
 
-void choose_radices(int log_n, std::vector<int>* out) {
+void choose_radices(int log_n, bool few, std::vector<int>* out) {
   out->clear();
   // experiments: STARKHIP_NTT_RADICES="10,10" (digits 2..11, at most 4 passes) applies to the sizes it sums to
   if (const char* e = getenv("STARKHIP_NTT_RADICES")) {
@@ -349,12 +349,14 @@ void choose_radices(int log_n, std::vector<int>* out) {
   }
   // Two passes of radix 2^9 / 2^10 (2048-element tiles) where they were measured ahead of three passes of 1024-element
   // tiles (one inter-pass twiddle modmul and one read + write of the vector fewer per transform; 2^18
-  // and everything from 2^21 up measured level or behind).  The matrix-core passes have no such radices: under
+  // and everything from 2^21 up measured level or behind).  `few` = the call transforms at most 2^21 elements.  The matrix-core passes have no such radices: under
   // STARKHIP_NTT_PATH=mfma the three-pass decomposition stays.
   if (!use_mfma_path()) {
     if (log_n == 17) { *out = {9, 8}; return; }
     if (log_n == 19) { *out = {9, 10}; return; }
-    if (log_n == 20) { *out = {10, 10}; return; }
+    // 2^20: two passes for one or two vectors per call (11.8 / 13.4 against 10.5 / 12.8 G elements/s), three passes of
+    // 1024-element tiles from four vectors up (14.7 / 14.8 against 13.9 / 14.3; level from 16 up)
+    if (log_n == 20 && few) { *out = {10, 10}; return; }
   }
   const int m = (log_n + 7) / 8, base = log_n / m, rem = log_n % m;
   for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));
@@ -409,8 +411,16 @@ int check_root_order(const fp& root, uint64_t n) {
   return fp_eq_canon(h, m1) ? SH_OK : SH_ERR_ROOT_ORDER;
 }
 
-int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** out) {
-  const std::string key = plan_key(root_eff, n, scaled);
+// a call that transforms at most 2^21 elements in all (batch = 0: unknown / not a transform -> the many-vector plan)
+bool few_vectors(uint64_t n, uint64_t batch) { return batch != 0 && batch <= (1ull << 21) / n; }
+
+int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, NttPlan** out) {
+  std::vector<int> radix;
+  choose_radices(ilog2(n), few, &radix);
+  std::vector<int> other;
+  choose_radices(ilog2(n), !few, &other);
+  // the two decompositions of a size are two plans (own twiddle tables); sizes with one decomposition share it
+  const std::string key = plan_key(root_eff, n, scaled) + ((radix != other && few) ? "f" : "");
   auto it = c->plans.find(key);
   if (it != c->plans.end()) {
     *out = it->second;
@@ -421,7 +431,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** o
   pl->log_n = ilog2(n);
   pl->scaled = scaled;
   pl->root = root_eff;
-  choose_radices(pl->log_n, &pl->radix);
+  pl->radix = radix;
   const size_t m = pl->radix.size();
   fp ninv = fp_one();
   if (scaled) ninv = h_pow(h_inv(fp_from_u32(2u)), (uint64_t)pl->log_n);  // n^-1 = (2^-1)^log_n
@@ -575,12 +585,12 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
   return SH_OK;
 }
 
-int plan_for(sh_ctx* c, const uint8_t root[32], uint64_t n, bool inverse, NttPlan** out) {
+int plan_for(sh_ctx* c, const uint8_t root[32], uint64_t n, bool inverse, NttPlan** out, uint64_t batch = 0) {
   if (!is_pow2(n) || n > (1ull << 32)) return n > (1ull << 32) ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
   fp w = h_from_wire(root);
   SH_TRY(check_root_order(w, n));
   if (inverse) w = h_pow(w, n - 1);  // w^-1: the reversed root list rootz[:0:-1] of fft.py:327
-  return get_plan(c, w, n, inverse, out);
+  return get_plan(c, w, n, inverse, few_vectors(n, batch), out);
 }
 
 uint64_t fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
@@ -699,7 +709,7 @@ int run_fri(sh_ctx* c, const fp* d_coeffs, uint64_t n, const uint8_t root[32], u
             uint32_t exclude, uint32_t samples, uint32_t batch, uint8_t* d_proof, uint64_t n_coeffs = 0) {
   if (!d_coeffs || !d_proof || batch == 0 || !is_pow2(n)) return SH_ERR_INVALID;
   NttPlan* pl = nullptr;
-  SH_TRY(plan_for(c, root, n, false, &pl));
+  SH_TRY(plan_for(c, root, n, false, &pl, batch));
   SH_TRY(fri_validate(n, maxdeg_plus_1, exclude, samples));
   FriBuffers fb;
   SH_TRY(fri_buffers(c, n, batch, samples, &fb));
@@ -826,9 +836,9 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   h_to_wire(g2, g2b);
   h_to_wire(h_pow(g2, ext), g1b);                          // G1 = G2^ext (stark.py:208)
   NttPlan *fwd_n, *inv_s, *fwd_s;
-  SH_TRY(plan_for(c, g2b, n, false, &fwd_n));
-  SH_TRY(plan_for(c, g1b, steps, true, &inv_s));
-  SH_TRY(plan_for(c, g1b, steps, false, &fwd_s));
+  SH_TRY(plan_for(c, g2b, n, false, &fwd_n, cols));
+  SH_TRY(plan_for(c, g1b, steps, true, &inv_s, cols));
+  SH_TRY(plan_for(c, g1b, steps, false, &fwd_s, cols));
   const fp g1 = h_pow(g2, ext);
   const fp x_last = h_pow(g2, (steps - 1) * ext);          // stark.py:212
   const fp inv_last_m1 = h_inv(fp_sub(x_last, fp_one()));
@@ -1123,7 +1133,7 @@ int sh_dev_ntt(sh_ctx* c, const void* d_in, void* d_out, uint64_t n, uint32_t ba
   if (!c || !d_in || !d_out || !root) return SH_ERR_INVALID;
   SH_TRY(enter(c));
   NttPlan* pl = nullptr;
-  SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
+  SH_TRY(plan_for(c, root, n, inverse != 0, &pl, batch));
   return run_ntt(c, pl, reinterpret_cast<const fp*>(d_in), reinterpret_cast<fp*>(d_out), batch);
 }
 int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t ext, uint32_t cols, const uint8_t g2[32]) {
@@ -1131,10 +1141,10 @@ int sh_dev_lde(sh_ctx* c, void* d_trace, void* d_out, uint64_t steps, uint32_t e
   SH_TRY(enter(c));
   const uint64_t n = steps * ext;
   NttPlan *inv1 = nullptr, *fwd2 = nullptr;
-  SH_TRY(plan_for(c, g2, n, false, &fwd2));
+  SH_TRY(plan_for(c, g2, n, false, &fwd2, cols));
   uint8_t g1b[32];
   h_to_wire(h_pow(fwd2->root, ext), g1b);  // G1 = G2^ext (stark.py:217-220)
-  SH_TRY(plan_for(c, g1b, steps, true, &inv1));
+  SH_TRY(plan_for(c, g1b, steps, true, &inv1, cols));
   fp* t = reinterpret_cast<fp*>(d_trace);
   fp* x = reinterpret_cast<fp*>(d_out);
   SH_TRY(run_ntt(c, inv1, t, t, cols));                                  // stark.py:27-36
@@ -1224,7 +1234,7 @@ int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint
   if (n_in > n) return SH_ERR_INVALID;
   SH_TRY(enter(c));
   NttPlan* pl = nullptr;
-  SH_TRY(plan_for(c, root, n, inverse != 0, &pl));
+  SH_TRY(plan_for(c, root, n, inverse != 0, &pl, batch));
   fp* x = nullptr;
   uint64_t n_short = 0;
   SH_TRY(upload_short(c, in, n_in, n, batch, sh_ctx::WS_X, &x, &n_short));
@@ -1247,8 +1257,8 @@ int sh_mul_polys(sh_ctx* c, const uint8_t* a, uint64_t n_a, const uint8_t* b, ui
   if (!c || !out || !root || (n_a && !a) || (n_b && !b) || n_a > n || n_b > n) return SH_ERR_INVALID;
   SH_TRY(enter(c));
   NttPlan *fwd = nullptr, *rev = nullptr;
-  SH_TRY(plan_for(c, root, n, false, &fwd));
-  SH_TRY(get_plan(c, h_pow(fwd->root, n - 1), n, false, &rev));  // reversed roots, NO 1/n (fft.py:345)
+  SH_TRY(plan_for(c, root, n, false, &fwd, 1));
+  SH_TRY(get_plan(c, h_pow(fwd->root, n - 1), n, false, few_vectors(n, 1), &rev));  // reversed roots, NO 1/n (fft.py:345)
   fp *x = nullptr, *y = nullptr;
   SH_TRY(upload_padded(c, a, n_a, n, 1, sh_ctx::WS_X, &x));
   SH_TRY(upload_padded(c, b, n_b, n, 1, sh_ctx::WS_Y, &y));
@@ -1276,10 +1286,10 @@ int sh_lde(sh_ctx* c, const uint8_t* trace, uint8_t* out, uint64_t steps, uint32
   SH_TRY(enter(c));
   const uint64_t n = steps * ext;
   NttPlan *inv1 = nullptr, *fwd2 = nullptr;
-  SH_TRY(plan_for(c, g2, n, false, &fwd2));
+  SH_TRY(plan_for(c, g2, n, false, &fwd2, cols));
   uint8_t g1b[32];
   h_to_wire(h_pow(fwd2->root, ext), g1b);  // G1 = G2^ext (stark.py:217-220)
-  SH_TRY(plan_for(c, g1b, steps, true, &inv1));
+  SH_TRY(plan_for(c, g1b, steps, true, &inv1, cols));
   fp* t = nullptr;
   SH_TRY(upload_padded(c, trace, steps, steps, cols, sh_ctx::WS_Y, &t));
   SH_TRY(run_ntt(c, inv1, t, t, cols));  // trace polynomial coefficients (stark.py:27-36)
@@ -1345,10 +1355,10 @@ int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root
   return download_wire(c, reinterpret_cast<fp*>(col), column, n / 4);
 }
 
-uint32_t sh_ntt_passes(uint64_t n) {
+uint32_t sh_ntt_passes(uint64_t n, uint32_t batch) {
   if (!is_pow2(n) || n > (1ull << 32)) return 0;
   std::vector<int> r;
-  choose_radices(ilog2(n), &r);
+  choose_radices(ilog2(n), few_vectors(n, batch), &r);
   return (uint32_t)r.size();
 }
 

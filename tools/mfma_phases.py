@@ -15,7 +15,7 @@ dev.ck(L.sh_dev_fill_seeded(ctx, dx, n * batch, 0x5eed), "fill")
 for _ in range(3):
     dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, batch, w, 0), "ntt")
 dev.sync()
-print("passes:", L.sh_ntt_passes(n), " recorded pass:", os.environ.get("STARKHIP_STAMP_PASS", "last"))
+print("passes:", L.sh_ntt_passes(n, 0), " recorded pass:", os.environ.get("STARKHIP_STAMP_PASS", "last"))
 buf = (ctypes.c_ulonglong * (8 * 1024))()
 L.sh_debug_stamps.argtypes = [ctypes.c_void_p]
 assert L.sh_debug_stamps(buf) == 0
