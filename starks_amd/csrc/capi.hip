@@ -265,7 +265,9 @@ int tw2_max_log() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_TW2_MAX_LOG");
-    v = e ? atoi(e) : 22;  // measured: +5..9 % up to 2^20-entry tables; a 2^24-entry (512 MiB) table gains nothing
+    // measured: +5..9 % up to 2^20-entry tables; with the twiddle loads requested ahead of use a 2^23-entry table (256 MiB,
+    // the first pass of the 2^23-point transform of a 2^20-step FRI commit) gains 4 %, a 2^24-entry one (512 MiB) 1-2 %
+    v = e ? atoi(e) : 23;
     if (v < 0) v = 0;
     if (v > 28) v = 28;
   }
@@ -486,7 +488,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         // the tile passes read their inter-pass twiddles g^(j2 k) as rows of adjacent columns: a [k][j2] copy of the
         // table, tw2[k * S + j2] -- one coalesced load per element instead of a scattered one (plus, above 2^18
         // entries, the second modmul of the two-half lookup).  n / P entries: 32 MiB for the first pass of 2^20 points;
-        // above 2^22 entries (STARKHIP_TW2_MAX_LOG) the pass keeps the power-table lookup.
+        // above 2^23 entries (STARKHIP_TW2_MAX_LOG) the pass keeps the power-table lookup.
         fp* tw2 = nullptr;
         const int log_S = pl->log_n - log_P - r;
         if (rc == SH_OK && r + log_S <= tw2_max_log()) {
