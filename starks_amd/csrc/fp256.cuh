@@ -90,8 +90,27 @@ FP_HD uint32_t fp_sub_c_masked(fp& a, uint32_t m) {
 // A carry out of limb 7 is folded as + c (2^256 == c).  c has two limbs, so the fold touches limbs 0..1; a carry
 // out of limb 1 needs limb 1 >= 2^32 - 351 (probability ~1e-7 per lane): the propagation through limbs 2..7 and
 // the possible second wrap live behind a wave-uniform branch that is almost never taken.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SHK_NO_ADD_ASM)
+#include "fp256_addasm.inc"  // fp_add_asm / fp_sub_asm: the common paths below as one asm statement each (gen_addasm.py)
+__device__ __forceinline__ uint32_t fp_lane_bit(uint64_t mask) {
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  return (uint32_t)(mask >> lane) & 1u;
+}
+#define FP_ADD_ASM 1
+#endif
+
 FP_HD fp fp_add(const fp& a, const fp& b) {
   fp r;
+#if defined(FP_ADD_ASM)
+  const uint64_t any = fp_add_asm(a, b, r);
+  if (any != 0) {  // scalar test: no VALU instruction on the common path
+    uint32_t c1 = fp_lane_bit(any);
+#pragma unroll
+    for (int i = 2; i < 8; ++i) r.v[i] = fp_addc(r.v[i], 0, c1, &c1);
+    fp_add_c_masked_low(r, c1);
+  }
+  return r;
+#else
   uint32_t cy = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = fp_addc(a.v[i], b.v[i], cy, &cy);
@@ -105,6 +124,7 @@ FP_HD fp fp_add(const fp& a, const fp& b) {
     fp_add_c_masked_low(r, c1);  // second wrap leaves r < 2^42, cannot wrap again
   }
   return r;
+#endif
 }
 
 // (a - b) mod p, lazily reduced.  modp.py:47-49.
@@ -113,6 +133,19 @@ FP_HD fp fp_add(const fp& a, const fp& b) {
 // means the value now is 2^256 - d with d < 2^41 and c is subtracted once more from limbs 0..1.
 FP_HD fp fp_sub(const fp& a, const fp& b) {
   fp r;
+#if defined(FP_ADD_ASM)
+  const uint64_t any = fp_sub_asm(a, b, r);
+  if (any != 0) {
+    uint32_t b1 = fp_lane_bit(any);
+#pragma unroll
+    for (int i = 2; i < 8; ++i) r.v[i] = fp_subb(r.v[i], 0, b1, &b1);
+    const uint32_t m2 = 0u - b1;
+    uint32_t b3;
+    r.v[0] = fp_subb(r.v[0], FP_C0 & m2, 0, &b3);
+    r.v[1] = fp_subb(r.v[1], FP_C1 & m2, b3, &b3);
+  }
+  return r;
+#else
   uint32_t bw = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r.v[i] = fp_subb(a.v[i], b.v[i], bw, &bw);
@@ -129,6 +162,7 @@ FP_HD fp fp_sub(const fp& a, const fp& b) {
     r.v[1] = fp_subb(r.v[1], FP_C1 & m2, b3, &b3);
   }
   return r;
+#endif
 }
 
 // unique residue in [0, p): subtract p once if a >= p (a < 2^256 < 2p).
