@@ -327,11 +327,19 @@ FP_HD fp fp_reduce_13(const uint32_t t[13]) {
   D[5] = A[4] - bd;
   fp r;
   uint32_t c = 0;
+#if defined(FP_ADD_ASM)
+  const uint64_t any = fp_add6_asm(t, D, r.v);
+  r.v[6] = t[6];
+  r.v[7] = t[7];
+  if (any != 0) {
+    c = fp_lane_bit(any);
+#else
 #pragma unroll
   for (int i = 0; i < 6; ++i) r.v[i] = fp_addc(t[i], D[i], c, &c);
   r.v[6] = t[6];
   r.v[7] = t[7];
   if (FP_ANY(c)) {
+#endif
     r.v[6] = fp_addc(r.v[6], 0u, c, &c);
     r.v[7] = fp_addc(r.v[7], 0u, c, &c);
     // c = 1: the sum passed 2^256 == c; what is left is below 2^171, so adding c cannot wrap again
