@@ -182,6 +182,17 @@ def test_reference_fft_unit_tests_on_other_fields():
     assert [int(v) for v in fft_1d(F, [0, 1, 2, 3], 31, w)] == g["fwd"]
 
 
+def test_generated_asm_includes_are_current(tmp_path):
+    """csrc/fp256_mulasm.inc and fp256_addasm.inc are committed outputs of gen_mulasm.py / gen_addasm.py (whose check() asserts
+    the carry wait states of every generated column): regenerating them must reproduce the committed files byte for byte."""
+    import shutil, subprocess, sys
+    csrc = os.path.join(ROOT, "starks_amd", "csrc")
+    for gen, inc in (("gen_mulasm.py", "fp256_mulasm.inc"), ("gen_addasm.py", "fp256_addasm.inc")):
+        shutil.copy(os.path.join(csrc, gen), tmp_path / gen)
+        subprocess.check_call([sys.executable, str(tmp_path / gen)])
+        assert (tmp_path / inc).read_bytes() == open(os.path.join(csrc, inc), "rb").read(), inc
+
+
 def test_pair_constant_product_on_the_host(tmp_path):
     """fp_mul2 (csrc/fp256.cuh: the product by a table constant kept as the pair (w, w 2^128 mod p), what every NTT
     butterfly uses) against fp_mul through the portable C paths of the same header: 400 k random and edge operands, canonical
