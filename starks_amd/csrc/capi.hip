@@ -852,7 +852,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   SH_TRY(ws_get(c, sh_ctx::WS_ST_B, cols * n * sizeof(fp), &bw));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_Q, cols * steps * sizeof(fp), &qv));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_MTREE, (size_t)batch * 2 * n * 32, &mt));
-  const size_t iab_bytes = cols * 2 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp);
+  const size_t iab_bytes = cols * 2 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp2);  // scalars as (s, s 2^128) pairs
   SH_TRY(ws_get(c, sh_ctx::WS_ST_SMALL, iab_bytes + scal_bytes + (size_t)batch * samples * 4, &small));
   fp* iab = reinterpret_cast<fp*>(small);
   fp* scal = reinterpret_cast<fp*>(reinterpret_cast<uint8_t*>(small) + iab_bytes);
@@ -952,8 +952,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   FriBuffers fb;
   SH_TRY(fri_buffers(c, n, batch, samples, &fb));
   HIP_TRY(c, shk_stark_scalars(mtree, 2 * n * 8, width, batch, cpow, scal, c->stream));
-  HIP_TRY(c, shk_stark_lincomb(a, scal, fb.vals, c->stream));
-  HIP_TRY(c, shk_merkelize(fb.vals, false, n, batch, fb.tree, c->stream, false));   // l_mtree
+  HIP_TRY(c, shk_stark_lincomb_tree(a, scal, fb.vals, fb.tree, c->stream));  // l and l_mtree = merkelize(l) in one pass
   // spot checks (stark.py:390-402)
   const uint64_t stride = stark_header_len(n, width, samples) + fri_proof_len(n, steps * (uint64_t)degree, 40);
   HIP_TRY(c, shk_sample_indices(fb.tree, 2 * n * 8, (uint32_t)n, batch, samples, ext, ys, c->stream));

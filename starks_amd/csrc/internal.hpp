@@ -148,6 +148,8 @@ hipError_t shk_stark_quotients(const StarkArgs& a, hipStream_t st);
 hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st);
 hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
                              fp* d_scal, hipStream_t st);
-hipError_t shk_stark_lincomb(const StarkArgs& a, const fp* d_scal, fp* d_l, hipStream_t st);
+// l = the Fiat-Shamir linear combination of P, D, B (scalars as (s, s 2^128) pairs) and the Merkle tree of l
+// (merkelize(l_evaluations)): the combination is fused with the tree's first three levels
+hipError_t shk_stark_lincomb_tree(const StarkArgs& a, const fp* d_scal, fp* d_l, uint32_t* d_lnodes, hipStream_t st);
 hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const fp* d_lvals,
                             const uint32_t* d_ys, uint32_t samples, uint8_t* d_proof, uint64_t stride, hipStream_t st);

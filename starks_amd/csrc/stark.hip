@@ -253,27 +253,86 @@ __global__ void __launch_bounds__(64) stark_scalars_kernel(const uint32_t* mnode
     const fp beta = fp_add(ks[0], fp_mul(ks[1], cpow));
     const fp gamma = fp_add(ks[2], fp_mul(ks[3], cpow));
     const fp alpha = fp_add(fp_one(), fp_mul(lk, cpow));
-    fp* o = scal + ((uint64_t)b * width + t) * 3;
-    fp_store(o, alpha);
-    fp_store(o + 1, fp_mul(alpha, beta));
-    fp_store(o + 2, fp_mul(alpha, gamma));
+    // each scalar with its image times 2^128: the combination multiplies by them through fp_mul2
+    fp two128 = fp_zero();
+    two128.v[4] = 1;
+    const fp sc[3] = {alpha, fp_mul(alpha, beta), fp_mul(alpha, gamma)};
+    fp* o = scal + ((uint64_t)b * width + t) * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      fp_store(o + 2 * k, sc[k]);
+      fp_store(o + 2 * k + 1, fp_mul(sc[k], two128));
+    }
   }
 }
-// l[b][i] = sum_j alpha_j D_j[i] + (alpha_j beta) P_j[i] + (alpha_j gamma) B_j[i]
-__global__ void __launch_bounds__(TPB) stark_lincomb_kernel(StarkArgs a, const fp* scal, fp* l_evals) {
-  const uint64_t N = a.n;
-  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= N * a.batch) return;
-  const uint64_t b = g / N, i = g - b * N;
-  fp acc = fp_zero();
-  for (uint32_t j = 0; j < a.width; ++j) {
-    const uint64_t col = (b * a.width + j) * N + i;
-    const fp* s = scal + (b * a.width + j) * 3;
-    acc = fp_add(acc, fp_mul(fp_load(s), fp_load(a.d_work + col)));
-    acc = fp_add(acc, fp_mul(fp_load(s + 1), fp_load(a.p_evals + col)));
-    acc = fp_add(acc, fp_mul(fp_load(s + 2), fp_load(a.b_work + col)));
+// l[b][i] = sum_j alpha_j D_j[i] + (alpha_j beta) P_j[i] + (alpha_j gamma) B_j[i] (stark.py:128-177),
+// fused with the first three levels of its Merkle tree (merkelize(l_evaluations),
+// stark.py:263 -> merkle_tree.py:36-56 with permute4): one thread per permute4 row i computes l at i, i + q, i + 2q, i + 3q,
+// stores the four values and hashes them on the spot -- the tree's leaf pass no longer reads l back, and its hashing runs in
+// the shadow of this kernel's memory traffic (the combination alone is HBM-bound).  nodes: [batch][2n] x 32 B as in
+// kernels.hip (the leaf level itself is not materialised: the branch gather re-derives leaves from l).
+template <int W>  // W = the width when it is 1 or 2 (all values of a point are requested before the first product), else 0
+__global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, const fp* scal, fp* l_evals, uint32_t* nodes) {
+  // the proof's 3 * width scalar pairs, staged in LDS once per workgroup (kept in registers they would cost 16 VGPRs each)
+  __shared__ uint4 sc_lds[9 * 3 * 4];
+  const uint64_t N = a.n, q = N >> 2;
+  const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  const uint64_t b = blockIdx.y;
+  const uint32_t width = W ? (uint32_t)W : a.width;
+  if (threadIdx.x < width * 12) sc_lds[threadIdx.x] = reinterpret_cast<const uint4*>(scal + b * width * 6)[threadIdx.x];
+  __syncthreads();
+  if (i >= q) return;
+  auto sc_pair = [&](uint32_t idx) {  // pair idx = 3 j + k
+    const uint4 q0 = sc_lds[4 * idx], q1 = sc_lds[4 * idx + 1], q2 = sc_lds[4 * idx + 2], q3 = sc_lds[4 * idx + 3];
+    fp2 r;
+    r.w.v[0] = q0.x; r.w.v[1] = q0.y; r.w.v[2] = q0.z; r.w.v[3] = q0.w;
+    r.w.v[4] = q1.x; r.w.v[5] = q1.y; r.w.v[6] = q1.z; r.w.v[7] = q1.w;
+    r.w128.v[0] = q2.x; r.w128.v[1] = q2.y; r.w128.v[2] = q2.z; r.w128.v[3] = q2.w;
+    r.w128.v[4] = q3.x; r.w128.v[5] = q3.y; r.w128.v[6] = q3.z; r.w128.v[7] = q3.w;
+    return r;
+  };
+  uint32_t* tree = nodes + b * 2 * N * 8;
+  uint32_t w[4][8];
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+    asm volatile("" ::: "memory");  // the scalar pairs are re-read from LDS every round, not kept live across the loop
+    const uint64_t x = i + (uint64_t)r * q;
+    fp acc = fp_zero();
+    if constexpr (W != 0) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        // the three values of a column are requested together, before their products (whose inline asm would otherwise pin
+        // every load right in front of its use)
+        const uint64_t col = (b * W + j) * N + x;
+        const fp v0 = fp_load(a.d_work + col), v1 = fp_load(a.p_evals + col), v2 = fp_load(a.b_work + col);
+        asm volatile("" ::: "memory");  // one scalar pair in registers at a time
+        acc = fp_add(acc, fp_mul2(v0, sc_pair(3u * j)));
+        asm volatile("" ::: "memory");
+        acc = fp_add(acc, fp_mul2(v1, sc_pair(3u * j + 1)));
+        asm volatile("" ::: "memory");
+        acc = fp_add(acc, fp_mul2(v2, sc_pair(3u * j + 2)));
+      }
+    } else {
+      for (uint32_t j = 0; j < width; ++j) {
+        const uint64_t col = (b * width + j) * N + x;
+        acc = fp_add(acc, fp_mul2(fp_load(a.d_work + col), sc_pair(3 * j)));
+        acc = fp_add(acc, fp_mul2(fp_load(a.p_evals + col), sc_pair(3 * j + 1)));
+        acc = fp_add(acc, fp_mul2(fp_load(a.b_work + col), sc_pair(3 * j + 2)));
+      }
+    }
+    fp_store(l_evals + b * N + x, acc);
+    fp_to_wire_words(fp_canon(acc), w[r]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
   }
-  fp_store(l_evals + g, acc);
+  const b2digest d0 = b2_hash_pair(w[0], w[1]);
+  const b2digest d1 = b2_hash_pair(w[2], w[3]);
+  store8(tree + (N / 2 + 2 * i) * 8, d0.h);
+  store8(tree + (N / 2 + 2 * i + 1) * 8, d1.h);
+  const b2digest d2 = b2_hash_pair(d0.h, d1.h);
+  store8(tree + (N / 4 + i) * 8, d2.h);
+  if (i == 0) {
+    uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    store8(tree, z);  // nodes[0]: the reference keeps b'' there
+  }
 }
 
 // ---- spot checks (stark.py:390-402) -------------------------------------------------------------------------
@@ -377,9 +436,18 @@ hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint
   return hipGetLastError();
 }
 
-hipError_t shk_stark_lincomb(const StarkArgs& a, const fp* d_scal, fp* d_l, hipStream_t st) {
-  hipLaunchKernelGGL(stark_lincomb_kernel, dim3(grid_for(a.n * a.batch)), dim3(TPB), 0, st, a, d_scal, d_l);
-  return hipGetLastError();
+hipError_t shk_stark_lincomb_tree(const StarkArgs& a, const fp* d_scal, fp* d_l, uint32_t* d_lnodes, hipStream_t st) {
+  if (a.n < 4) return hipErrorInvalidValue;
+  const dim3 grid(grid_for(a.n >> 2), a.batch);
+  if (a.width == 1)
+    hipLaunchKernelGGL(stark_lincomb_leaves_kernel<1>, grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);
+  else if (a.width == 2)
+    hipLaunchKernelGGL(stark_lincomb_leaves_kernel<2>, grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);
+  else
+    hipLaunchKernelGGL(stark_lincomb_leaves_kernel<0>, grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return shk_merkle_upper_levels(a.n, a.batch, d_lnodes, st);
 }
 
 hipError_t shk_stark_gather(const StarkArgs& a, const uint32_t* d_mnodes, const uint32_t* d_lnodes, const fp* d_lvals,
