@@ -415,7 +415,7 @@ def main():
                     "trace: one launch sequence covers all of them)")
     ap.add_argument("--units", type=int, default=None, help="c5: proofs in the batch (512; 16 with --quick)")
     ap.add_argument("--logsteps", type=int, default=None, help="c5: log2 trace length (16; 10 with --quick)")
-    ap.add_argument("--chunk", type=int, default=64, help="c5: proofs per batched launch")
+    ap.add_argument("--chunk", type=int, default=128, help="c5: proofs per batched launch")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="ntt: skip the many-proof leg")
     ap.add_argument("--no-single", action="store_true", help="ntt: skip the single-vector leg (profiling runs: keeps the "
