@@ -554,6 +554,26 @@ def test_rare_carry_branches(sa):
     mixed = filler[:30] + pairs + filler[30:]
     got = unwire(sa.fft.ntt_bytes(b"".join(wire([a, b]) for a, b in mixed), 2, P - 1, batch=len(mixed)))
     assert got == [v for a, b in mixed for v in ((a + b) % P, (a - b) % P)]
+    # fp_mul2 (the butterflies' product by a table pair, fp256.cuh): its fold carries out of limb 5 with probability 2^-22.
+    # A 4-point transform of [0, x, 0, 0] multiplies x by the 4th root of unity I = root_of(4) through it; these x were
+    # found by search (exact integers: the low 192 bits of x_lo I + x_hi (I 2^128 mod p) plus the folded top overflow).
+    rare = [0xff6a2ad1abf9806db549b1ee5fa97b878013931d44877dfc3495ef6a863f1f72,
+            0x73733a361e4774862b504d594c9ae08db9c050b30568b5b6e336370c0edcc14a]
+    I4 = root_of(4)
+    C = M - P
+    for x in rare:
+        t = (x & ((1 << 128) - 1)) * I4 + (x >> 128) * ((I4 << 128) % P)
+        assert ((t & ((1 << 192) - 1)) + (((t >> 256) * C) & ((1 << 192) - 1))) >> 192 == 1   # the vector does what it claims
+        out = unwire(sa.fft.ntt_bytes(wire([0, x, 0, 0]), 4, I4))
+        assert out == [x % P, x * I4 % P, (P - x) % P, (P - x) * I4 % P]
+    vecs = [[rng.randrange(M) for _ in range(4)] for _ in range(40)]
+    vecs[17] = [0, rare[0], 0, 0]
+    vecs[18] = [5, rare[1], 9, 0]
+    got = unwire(sa.fft.ntt_bytes(b"".join(wire(v) for v in vecs), 4, I4, batch=len(vecs)))
+    want = []
+    for v in vecs:
+        want += [sum(v[j] * pow(I4, j * k, P) for j in range(4)) % P for k in range(4)]
+    assert got == want
     # products through mul_polys with n = 1 (NTT of length 1 is the identity): x * y mod p
     L, ctx = sa.lib.lib(), sa.lib.ctx()
     for x, y in [(2 * H, 1 << 255), (M - 1, M - 1), (P - 1, P - 1), (H, 1 << 255), (2 * H + 1, (1 << 255) + 12345)]:
