@@ -30,6 +30,33 @@ int main() {
     if (memcmp(&a, &b, sizeof a)) ++bad;
     ++n;
   }
+  // operands found by search that take fp_reduce_13's rare branch (carry out of limb 5) with w = the 4th root of unity
+  {
+    const fp w4 = {{0xfa5aa3a4u, 0x377de0dfu, 0x4d7e179du, 0x2fad473cu, 0x455ace10u, 0x8a4103c1u, 0x19cb5303u, 0x4ed93a77u}};
+    const fp xs[2] = {{{0x863f1f72u, 0x3495ef6au, 0x44877dfcu, 0x8013931du, 0x5fa97b87u, 0xb549b1eeu, 0xabf9806du, 0xff6a2ad1u}}, {{0x0edcc14au, 0xe336370cu, 0x0568b5b6u, 0xb9c050b3u, 0x4c9ae08du, 0x2b504d59u, 0x1e477486u, 0x73733a36u}}};
+    fp2 ww;
+    ww.w = w4;
+    ww.w128 = fp_canon(fp_mul(w4, two128));
+    for (int k = 0; k < 2; ++k) {
+      uint32_t t[13];
+      fp_mul2_wide(xs[k].v, ww.w.v, ww.w128.v, t);
+      // the rare branch is taken iff lo[0..5] + D[0..5] carries: recompute the condition the slow way
+      unsigned __int128 acc = 0;
+      uint32_t A[5], D[6];
+      uint64_t cy = 0;
+      for (int i = 0; i < 5; ++i) { uint64_t m = (uint64_t)t[8 + i] * 351u + cy; A[i] = (uint32_t)m; cy = m >> 32; }
+      uint32_t bd = 0;
+      D[0] = fp_subb(0u, t[8], 0, &bd);
+      for (int i = 1; i < 5; ++i) D[i] = fp_subb(A[i - 1], t[8 + i], bd, &bd);
+      D[5] = A[4] - bd;
+      uint32_t c = 0;
+      for (int i = 0; i < 6; ++i) (void)fp_addc(t[i], D[i], c, &c);
+      (void)acc;
+      if (!c) { printf("vector %d does not take the rare branch\n", k); ++bad; }
+      const fp a = fp_canon(fp_mul(xs[k], w4)), b = fp_canon(fp_mul2(xs[k], ww));
+      if (memcmp(&a, &b, sizeof a)) ++bad;
+    }
+  }
   printf("%ld products, %ld mismatches\n", n, bad);
   return bad != 0;
 }
