@@ -158,8 +158,33 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   fp2 tw_cur, tw_nxt;
   if constexpr (first_tw < 4) tw_cur = tw_load(first_tw);
 
+  // ---- zero-padded source whose non-zero part ends inside the first quarter of the rows (the 8x low-degree extension:
+  // rows i >= R / 8 of every column are zero): this thread's elements 1..3 are zero, so the group's two levels are
+  //   x2 = x0 w_a,  x1 = x0 w_b,  x3 = x2 w_c   -- three products, no addition, nothing at all where x0 is zero too
+  bool sparse_done = false;
+  if constexpr (g == 0 && !LAST && LOG_R >= 4) {
+    if (a.src_n && a.src_n <= ((uint64_t)(R / 4) << a.log_S)) {
+      sparse_done = true;
+      const uint64_t off = ((uint64_t)th.ibase << a.log_S) + th.j2;  // element h = 0
+      const bool in = off < a.src_n;
+      th.x[0] = th.x[1] = th.x[2] = th.x[3] = fp_zero();
+      if (FP_ANY(in)) {  // wave-uniform
+        fp x0 = fp_load(a.src + th.sbase + (in ? off : 0));
+        const fp2 tw_b = tw_load(2), tw_c = tw_load(3);  // tw_cur holds butterfly 0's
+#pragma unroll
+        for (int w = 0; w < 8; ++w) x0.v[w] = in ? x0.v[w] : 0u;
+        th.x[0] = x0;
+        th.x[2] = fp_mul2(x0, tw_cur);
+        th.x[1] = fp_mul2(x0, tw_b);
+        th.x[3] = fp_mul2(th.x[2], tw_c);
+      }
+    }
+  }
+
   // ---- fetch this group's four elements ---------------------------------------------------------
-  if (g == 0) {
+  if (sparse_done) {
+    // nothing left to do before the exchange
+  } else if (g == 0) {
     if (a.src_n) {  // zero-padded source (first pass only): points at or beyond src_n are zero and are not read
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
@@ -185,7 +210,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   }
 
   // ---- butterfly levels (DIF: a' = a + b, b' = (a - b) * w^((i mod half) * 2^s)) ---------------------
-  static_for4([&](auto bc) {
+  if (!sparse_done) static_for4([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     constexpr int q = qhi - (b >> 1), pr = b & 1;
     if constexpr (q >= 0) {
