@@ -88,8 +88,8 @@ class Dev:
 # config 5: many independent STARK proofs, sharded by proof index
 # ---------------------------------------------------------------------------------------------------------------------
 class ProofShard:
-    """This rank's units of the many-proof workload, resident in HBM: pristine witnesses (generated on the device,
-    untimed), one work buffer per chunk (the prover overwrites its witness), the flat proofs of the whole shard."""
+    """This rank's units of the many-proof workload, resident in HBM: the witnesses (generated on the device,
+    untimed; the prover leaves them intact) and the flat proofs of the whole shard."""
 
     def __init__(self, dev, units, steps, ext=8, chunk=32):
         from starks_amd import stark
@@ -105,7 +105,6 @@ class ProofShard:
         self.wbytes = 64 * steps  # one unit's witness: 2 columns
         self.d_wit = dev.alloc(self.wbytes * k)
         self.d_inp = dev.alloc(64 * k)
-        self.d_work = dev.alloc(self.wbytes * chunk)
         self.d_proofs = dev.alloc(self.plen * k)
         if self.units:  # shards are contiguous ranges (batch.shard)
             assert self.units == list(range(self.units[0], self.units[0] + len(self.units)))
@@ -117,9 +116,8 @@ class ProofShard:
         dev, L, ctx = self.dev, self.dev.L, self.dev.ctx
         for c in range(0, len(self.units), self.chunk):
             k = min(self.chunk, len(self.units) - c)
-            # the prover consumes its witness: take a copy of the pristine one (device to device, part of the step)
-            dev.ck(L.sh_dev_copy(ctx, ctypes.c_void_p(self.d_wit.value + self.wbytes * c), self.d_work, self.wbytes * k), "copy")
-            dev.ck(L.sh_dev_stark_prove(ctx, self.d_work, ctypes.c_void_p(self.d_inp.value + 64 * c), self.steps, self.ext, 2,
+            dev.ck(L.sh_dev_stark_prove(ctx, ctypes.c_void_p(self.d_wit.value + self.wbytes * c),
+                                        ctypes.c_void_p(self.d_inp.value + 64 * c), self.steps, self.ext, 2,
                                         self.coefs, self.exps, self.counts, 80, k,
                                         ctypes.c_void_p(self.d_proofs.value + self.plen * c)), "stark prove")
 
@@ -140,7 +138,7 @@ class ProofShard:
         return out.raw
 
     def close(self):
-        for p in (self.d_wit, self.d_inp, self.d_work, self.d_proofs):
+        for p in (self.d_wit, self.d_inp, self.d_proofs):
             self.dev.free(p)
 
 

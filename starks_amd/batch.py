@@ -141,7 +141,7 @@ class StarkUnitProver(object):
                         "sh_dev_fill_mimc_units")
 
     def prove(self, k):
-        """The prover overwrites its witness: generate() again before the next prove()."""
+        """Proves the k units generate() left on the device (the witness is read only and can be proved again)."""
         self._lib.check(self.L.sh_dev_stark_prove(self.ctx, self.dw, self.di, self.steps, self.ext, 2, self.coefs, self.exps,
                                                   self.counts, 80, k, self.dp), "sh_dev_stark_prove")
 

@@ -910,6 +910,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   a.d_work = reinterpret_cast<fp*>(dw);
   a.b_work = reinterpret_cast<fp*>(bw);
   a.q_evals = reinterpret_cast<fp*>(qv);
+  a.wit = d_wit;
   a.iab = iab;
   a.n = n;
   a.steps = steps;
@@ -938,10 +939,12 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   // boundary interpolants need witness[dim][-1] before the trace becomes coefficients (stark.py:91-96)
   HIP_TRY(c, shk_stark_interp(d_wit, d_inputs, steps, (uint32_t)cols, inv_last_m1, iab, c->stream));
   // trace polynomials and their evaluations: the low-degree extension (stark.py:27-36, 253-256)
-  SH_TRY(run_ntt(c, inv_s, d_wit, d_wit, (uint32_t)cols));
-  SH_TRY(run_ntt(c, fwd_n, d_wit, P, (uint32_t)cols, steps));  // the zero padding of fft_1d is implicit (fft.py:323-324)
+  // (coefficients go to the Q buffer: the witness stays what it is -- the trace polynomials' values on the trace points,
+  // which the trace-point kernel reads contiguously)
+  SH_TRY(run_ntt(c, inv_s, d_wit, Q, (uint32_t)cols));
+  SH_TRY(run_ntt(c, fwd_n, Q, P, (uint32_t)cols, steps));  // the zero padding of fft_1d is implicit (fft.py:323-324)
   // Q = X P'(X) on the trace points, for the quotients' values there
-  HIP_TRY(c, shk_stark_qprep(d_wit, Q, steps, cols, c->stream));
+  HIP_TRY(c, shk_stark_qprep(Q, Q, steps, cols, c->stream));
   SH_TRY(run_ntt(c, fwd_s, Q, Q, (uint32_t)cols));
   // D = C / Z and B = (P - I) / Z2 (stark.py:38-104), evaluated on the whole domain
   HIP_TRY(c, shk_stark_quotients(a, c->stream));

@@ -113,6 +113,8 @@ struct StarkArgs {
   fp* d_work;         // [batch * width][n]  D evaluations
   fp* b_work;         // [batch * width][n]  B evaluations
   const fp* q_evals;  // [batch * width][steps]  Q_c = X P_c'(X) on G1
+  const fp* wit;      // [batch * width][steps]  the witness itself = the trace polynomials on G1 (read contiguously by the
+                      // trace-point kernel instead of every ext-th entry of p_evals)
   const fp* iab;      // [batch * width][2]  boundary interpolant a + b X
   uint64_t n;         // precision = steps * ext
   uint64_t steps;

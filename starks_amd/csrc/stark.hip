@@ -140,12 +140,12 @@ __global__ void __launch_bounds__(TPB) stark_trace_points_kernel(StarkArgs a) {
   const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   if (g >= s * a.batch) return;
   const uint64_t b = g / s, k = g - b * s;
-  const uint64_t i = k * a.ext, knext = (k + 1) & (s - 1), inext = knext * a.ext;
-  const fp* pe = a.p_evals + b * W * N;
+  const uint64_t i = k * a.ext, knext = (k + 1) & (s - 1);
+  const fp* we = a.wit + b * W * s;  // P_v(x_k) = witness[v][k]
   const fp* qe = a.q_evals + b * W * s;
   fp P[W];
 #pragma unroll
-  for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + i);
+  for (int v = 0; v < W; ++v) P[v] = fp_load(we + (uint64_t)v * s + k);
   const fp x = pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i);
   const bool last = knext == 0;
   const fp scale = fp_mul(last ? a.x_last : fp_sub(x, a.x_last), a.inv_steps);
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(TPB) stark_trace_points_kernel(StarkArgs a) {
   for (int c = 0; c < W; ++c) {
     const uint64_t col = (b * W + c) * N;
     const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], P);
-    const fp cval = fp_sub(fp_load(pe + (uint64_t)c * N + inext), acc);  // witness[c][k+1] - step_c(witness[.][k])
+    const fp cval = fp_sub(fp_load(we + (uint64_t)c * s + knext), acc);  // witness[c][k+1] - step_c(witness[.][k])
     fp num;
     if (last) {
       num = cval;  // Z(r) = s / r is not zero: D(r) = C(r) r / s
