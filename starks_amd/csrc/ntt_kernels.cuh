@@ -78,6 +78,62 @@ struct TileThread {
   uint64_t sbase;  // zero-padded source (a.src_n != 0): element offset of (this column/row, i = 0) in the short source
 };
 
+// ---- which thread holds which elements ---------------------------------------------------------------------------------
+// In group g a thread holds the four elements whose row index i differs in the bits (beta, beta + 1) of the group's two
+// levels; the other LOG_R - 2 bits of i (and the column t) name the thread.  WAVE-LOCAL EXCHANGES: the groups fall into
+// two phases.  Phase 0 (the first GA groups, whose level bits are the top 2 GA bits of i) takes the wave number from i
+// bits BELOW its level bits, phase 1 (the rest) from the TOP bits of i, which its levels never touch.  Inside a phase an
+// element therefore stays in the same wave from group to group: the hand-over through LDS needs no workgroup barrier (the
+// LDS unit serves a wave's requests in order), only the phase change does -- one __syncthreads() per tile instead of one
+// per group, and waves that drift apart instead of marching in step.  (SHK_WAVE_LOCAL=0: the plain mapping, a barrier per
+// exchange.)
+#ifndef SHK_WAVE_LOCAL
+#define SHK_WAVE_LOCAL 1
+#endif
+template <int LOG_R, int LOG_T>
+__host__ __device__ constexpr bool tile_wave_local() {
+  constexpr int LOG_W = LOG_R + LOG_T - 8;  // log2 of the waves per workgroup
+  if (!SHK_WAVE_LOCAL || LOG_W < 0 || LOG_T > 5 || LOG_R < 4) return false;
+  constexpr int GA = (LOG_W + 1) / 2;
+  return LOG_W <= LOG_R - 2 * GA;
+}
+// phase of group g: -1 = the row pass's first group (its own lane mapping), 0 / 1 as above
+template <int LOG_R, int LOG_T, bool LAST>
+__host__ __device__ constexpr int tile_phase(int g) {
+  if (LAST && g == 0) return -1;
+  if (!tile_wave_local<LOG_R, LOG_T>()) return 2 + g;  // every exchange crosses waves
+  constexpr int LOG_W = LOG_R + LOG_T - 8;
+  return g < (LOG_W + 1) / 2 ? 0 : 1;
+}
+// row index (with the group's two level bits clear) of the elements of thread tid in group g (not the row pass's group 0)
+template <int LOG_R, int LOG_T, int g>
+__device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
+  constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;
+  if constexpr (!tile_wave_local<LOG_R, LOG_T>()) {
+    const uint32_t rest = tid >> LOG_T;
+    return ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
+  } else {
+    constexpr int LOG_W = LOG_R + LOG_T - 8;
+    constexpr int GA = (LOG_W + 1) / 2;
+    constexpr int wlo = g < GA ? (LOG_R - 2 * GA) - LOG_W : LOG_R - LOG_W;  // the wave number sits at i bits [wlo, wlo + LOG_W)
+    const uint32_t lane_i = (tid & 63u) >> LOG_T, wave = tid >> 6;
+    uint32_t i = 0;
+    int nl = 0, nw = 0;
+#pragma unroll
+    for (int p = 0; p < LOG_R; ++p) {
+      if (p == beta || p == beta + 1) continue;
+      if (p >= wlo && p < wlo + LOG_W) {
+        i |= ((wave >> nw) & 1u) << p;
+        ++nw;
+      } else {
+        i |= ((lane_i >> nl) & 1u) << p;
+        ++nl;
+      }
+    }
+    return i;
+  }
+}
+
 // Register group g: fetch 4 elements (global memory for g == 0, LDS otherwise), do its butterfly levels,
 // and hand the elements to the next group through LDS.
 template <int LOG_R, int LOG_T, bool LAST, int g>
@@ -87,15 +143,14 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   constexpr int G = (LOG_R + 1) / 2;
   constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;  // position of local bit 0
   constexpr bool rfast = LAST && g == 0;  // row pass loads: lanes run along the contiguous row
-  uint32_t rest;
   if (rfast) {
-    rest = tid & (R / 4 - 1);
+    const uint32_t rest = tid & (R / 4 - 1);
     th.t = tid >> (LOG_R - 2);
+    th.ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
   } else {
     th.t = tid & (T - 1);
-    rest = tid >> LOG_T;
+    th.ibase = tile_ibase<LOG_R, LOG_T, g>(tid);
   }
-  th.ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
 
   if (g == 0 || (LAST && g == 1)) {
     // (re)derive the global coordinates of this thread's column/row: t changes between the
@@ -238,7 +293,14 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     for (int h = 0; h < 4; ++h) {
       lds_put_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)), th.x[h]);
     }
-    __syncthreads();
+    if constexpr (tile_phase<LOG_R, LOG_T, LAST>(g) == tile_phase<LOG_R, LOG_T, LAST>(g + 1)) {
+      // the next group's elements were written by lanes of this wave: order the wave's own LDS traffic, nothing more
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+    }
   }
 }
 
@@ -275,7 +337,7 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
   // once, or two, cost a wave per SIMD (106 / 102 VGPRs) and measured slower on single vectors and on 2^24.
   fp itw[4];
   auto itw_load = [&](int h) {
-    const uint32_t i = ((tid >> LOG_T) << 2) | (uint32_t)h;  // the last group's element index (beta = 0)
+    const uint32_t i = tile_ibase<LOG_R, LOG_T, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
     const uint32_t k = __brev(i) >> (32 - LOG_R);
     return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
   };
