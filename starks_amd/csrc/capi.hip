@@ -350,15 +350,19 @@ void choose_radices(int log_n, bool few, std::vector<int>* out) {
     return;
   }
   // Two passes of radix 2^9 / 2^10 (2048-element tiles) where they were measured ahead of three passes of 1024-element
-  // tiles (one inter-pass twiddle modmul and one read + write of the vector fewer per transform; 2^18
-  // and everything from 2^21 up measured level or behind).  `few` = the call transforms at most 2^21 elements.  The matrix-core passes have no such radices: under
+  // tiles (one inter-pass twiddle modmul and one read + write of the vector fewer per transform;
+  // everything from 2^21 up measured behind).  The matrix-core passes have no such radices: under
   // STARKHIP_NTT_PATH=mfma the three-pass decomposition stays.
   if (!use_mfma_path()) {
+    // measured with the final kernels (wave-local exchanges), forward + inverse, against the three-pass plans of 1024-element
+    // tiles: 2^20 12.3 / 14.1 / 14.5 / 15.5 / 16.1 / 16.5 vs 10.6 / 13.0 / 14.7 / 15.2 / 15.6 / 15.9 G elements/s at 1 / 2 / 4 / 8 / 16 / 32
+    // vectors; 2^18 (9, 9) 14.4 / 17.0 / 18.2 vs 14.3 / 16.7 / 17.7 at 8 / 32 / 128.  `few` (a call of at most 2^21 elements) no
+    // longer selects a different plan; the parameter stays for sizes where it may.
+    (void)few;
     if (log_n == 17) { *out = {9, 8}; return; }
+    if (log_n == 18) { *out = {9, 9}; return; }
     if (log_n == 19) { *out = {9, 10}; return; }
-    // 2^20: two passes for one or two vectors per call (11.8 / 13.4 against 10.5 / 12.8 G elements/s), three passes of
-    // 1024-element tiles from four vectors up (14.7 / 14.8 against 13.9 / 14.3; level from 16 up)
-    if (log_n == 20 && few) { *out = {10, 10}; return; }
+    if (log_n == 20) { *out = {10, 10}; return; }
   }
   const int m = (log_n + 7) / 8, base = log_n / m, rem = log_n % m;
   for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));

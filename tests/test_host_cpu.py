@@ -277,7 +277,7 @@ int main(void) {
   if (sh_stark_proof_len(8, 8, 2, 3, 80) != 147808) return 4;   /* tests/golden/stark.json: mimc_w2_s8 */
   if (sh_stark_proof_len(8, 8, 10, 3, 80) != 0) return 5;
   if (sh_ntt(NULL, NULL, 0, NULL, 8, NULL, 0) != SH_ERR_INVALID) return 6;
-  if (sh_ntt_passes(1u << 20, 1) != 2 || sh_ntt_passes(1u << 20, 8) != 3 || sh_ntt_passes(1u << 19, 64) != 2 || sh_ntt_passes(1u << 24, 1) != 3 ||
+  if (sh_ntt_passes(1u << 20, 1) != 2 || sh_ntt_passes(1u << 20, 8) != 2 || sh_ntt_passes(1u << 19, 64) != 2 || sh_ntt_passes(1u << 24, 1) != 3 ||
       sh_ntt_passes(256, 1) != 1 || sh_ntt_passes(6, 1) != 0) return 7;
   if (sh_ctx_trim(NULL) != SH_ERR_INVALID || sh_stark_status_batch(NULL, NULL, 0) != SH_ERR_INVALID) return 8;
   printf("ok\n");
