@@ -1023,6 +1023,17 @@ def test_alternate_ntt_plans_parity(sa, env):
     assert " passed" in out.stdout
 
 
+def test_random_plan_variants_vs_oracle(sa):
+    """tools/stress_plans.py for a few seconds: random decompositions (digits 2..11, one to four passes), tile sizes and tile orders,
+    each in a child process, random sizes / batches / zero padding / direction, every output against oracle/oracle.c.  (The
+    full run -- 1005 variants in 7 minutes, all equal -- is recorded in DESIGN.md section 3.)"""
+    import subprocess, sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_plans.py"), "10"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "all outputs equal to the oracle" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_pinned_host_buffers_skip_staging(sa):
     """sh_host_alloc buffers go through the host-buffer entry points without the staging copy and give the same bytes."""
     n = 1 << 14
