@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised NTT differential test over forced plan / tile variants (GPU box): for each variant a child process transforms random
 vectors of random sizes and batches (forward, inverse, zero-padded) and compares every output with oracle/oracle.c.
-usage: stress_plans.py [seconds]"""
+usage: stress_plans.py [seconds [min_logn max_logn [transforms_per_variant]]]"""
 import os, random, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -31,17 +31,20 @@ def parts(total, k, lo=2, hi=11, rng=random):
         if sum(r) == total:
             return r
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+lo_n = int(sys.argv[2]) if len(sys.argv) > 3 else 4
+hi_n = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+per = sys.argv[4] if len(sys.argv) > 4 else "6"
 rng = random.Random(20261004)
 t0 = time.time(); runs = 0
 while time.time() - t0 < budget:
-    logn = rng.randint(4, 16)
+    logn = rng.randint(lo_n, hi_n)
     k = rng.choice([1, 2, 2, 3, 3, 4])
     if logn < 2 * k or logn > 11 * k:
         continue
     rad = parts(logn, k, rng=rng)
     env = dict(os.environ, STARKHIP_NTT_RADICES=",".join(map(str, rad)), STARKHIP_TILE_LOG=str(rng.choice([9, 10, 11])),
                STARKHIP_TILE_LOG_BIG=str(rng.choice([10, 11, 12])), STARKHIP_XCD_SWZ=str(rng.choice([0, 1, 2, 3])))
-    out = subprocess.run([sys.executable, "-c", CHILD, str(rng.randrange(1 << 30)), str(logn), "6"], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", CHILD, str(rng.randrange(1 << 30)), str(logn), per], env=env, capture_output=True, text=True, timeout=300)
     runs += 1
     if out.returncode != 0 or "ok" not in out.stdout:
         print("FAILED", logn, rad, {k: v for k, v in env.items() if k.startswith("STARKHIP")}, out.stdout[-500:], out.stderr[-1500:])
