@@ -7,16 +7,17 @@ Launch.  With --gpus N > 1 and no torch.distributed environment, bench.py starts
 (`python -m torch.distributed.run`, one process per GPU, as a CHILD process and before this process touches the GPU);
 launched by the driver through torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
-Workload `ntt` (default; BASELINE.json's metric, configs[1]): a 2^20-point forward NTT followed by the inverse NTT
-over the MiMC prime, data resident in HBM, `--batch` (8) independent vectors per step per GPU -- the columns of a
-trace, one launch sequence covers all of them.  Ranks transform their own vectors: weak scaling, no data-path
-collective.  `value` = transformed elements of all ranks / max-over-ranks time.  The literal single-vector
-configs[1] figure and the metric's second half (FRI commit of a 2^20-step trace) are the top-level keys
-`single_vector_elements_per_s` and `fri_commit_ms_2^20_trace` (rank 0, N = 1).
+Workload `ntt` (default; BASELINE.json's metric on configs[3], the largest single-GPU configuration and the one the
+HBM-roofline target is quoted on): ONE 2^24-point forward NTT followed by the inverse NTT over the MiMC prime, data
+resident in HBM (`--logn`, `--batch` select other shapes: `--logn 20 --batch 8` is the trace-columns shape).  Ranks
+transform their own vectors: weak scaling, no data-path collective.  `value` = transformed elements of all
+ranks / max-over-ranks time.  The other shapes of the metric are top-level keys measured after the timed region (rank 0,
+N = 1): `single_vector_elements_per_s` (configs[1] literally: one 2^20-point pair), `ntt_2^20_x8_elements_per_s` (8 trace
+columns per launch sequence), `fri_commit_ms_2^20_trace` / `fri_commit_ms_2^14_trace` (the metric's second half).
 
 Workload `c5` (BASELINE configs[4]): `--units` (512) independent 2^16-step MiMC STARK proofs (STARK.mk_proof,
 stark.py:233-279; unit j = test_stark.py:265-293 started from 3 + j), sharded over the ranks by proof index
-(starks_amd/batch.py:shard), 64 proofs per batched launch; a step = the whole batch once; `value` = proofs/s; strong
+(starks_amd/batch.py:shard), `--chunk` (128) proofs per batched launch; a step = the whole batch once; `value` = proofs/s; strong
 scaling; the only exchange is one all_gather of the 64-byte proof headers (m_root | l_root) per step (RCCL).  Every run of
 the default workload also runs three such steps after its timed region and reports it under `c5` / `c5_proofs_per_s`, so
 that the driver's N = 1, 2, 4, 8 runs record the proofs/s curve too.
@@ -26,9 +27,10 @@ Also on the line:
                    library's stream.
   cpu_baseline  -- the C oracle (oracle/oracle.c: the reference's recursive algorithm) on a bounded sample of the same
                    workload, rank 0 at N = 1 only.
-  extra         -- 2^24-point NTT (config 4), FRI commits, Merkle commit of 2^24 leaves, whole STARK proofs.
+  extra         -- FRI commits, Merkle commit of 2^24 leaves, LDE, whole STARK proofs.
 """
 import argparse
+import datetime
 import ctypes
 import hashlib
 import json
@@ -91,7 +93,7 @@ class ProofShard:
     """This rank's units of the many-proof workload, resident in HBM: the witnesses (generated on the device,
     untimed; the prover leaves them intact) and the flat proofs of the whole shard."""
 
-    def __init__(self, dev, units, steps, ext=8, chunk=32):
+    def __init__(self, dev, units, steps, ext=8, chunk=128):
         from starks_amd import stark
         from starks_amd.modp import IntegersModP
         from starks_amd.multivariate_polynomial import generate_Xi_s
@@ -187,40 +189,6 @@ def extras(dev, quick):
     """Secondary legs, rank 0 at N=1 only (not part of `value`)."""
     L, ctx = dev.L, dev.ctx
     out = {}
-    # ---- config 4: 2^24-point NTT ------------------------------------------------------------------
-    for logn in ([22] if quick else [24]):
-        n = 1 << logn
-        w = root_of(n).to_bytes(32, "big")
-        dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
-        dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed), "fill")
-        for _ in range(3):  # plan tables + clocks settled before the timed forward transforms
-            dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt")
-        ms = dev.timed(lambda: dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"), 20)
-        # reference-independent pin: the forward digest against the C oracle's (tests/golden/ntt_large.json)
-        whole = ctypes.create_string_buffer(32 * n)
-        dev.ck(L.sh_dev_to_wire(ctx, dy, whole, n), "dl")
-        sha = hashlib.sha256(whole.raw).hexdigest()
-        del whole
-        pin = None
-        try:
-            for c in json.load(open(os.path.join(ROOT, "tests", "golden", "ntt_large.json")))["cases"]:
-                if c["n"] == n:
-                    pin = c["sha_fwd"] == sha
-        except Exception:
-            pass
-        # size-independent check: inverse brings the input back
-        dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")
-        chk = 1 << 16
-        a, b = ctypes.create_string_buffer(32 * chk), ctypes.create_string_buffer(32 * chk)
-        dev.ck(L.sh_dev_to_wire(ctx, dx, a, chk), "dl")
-        dev.ck(L.sh_dev_to_wire(ctx, dy, b, chk), "dl")
-        out["ntt_2^%d" % logn] = {
-            "ms": round(ms, 4), "elements_per_s": n / ms * 1e3,
-            "field_mul_eq_per_s": (n // 2) * logn / ms * 1e3,
-            "algorithmic_GBps": 64.0 * n / ms / 1e6, "hbm_frac": 64.0 * n / ms / 1e6 / HBM_PEAK_GBS,
-            "roundtrip_ok": a.raw == b.raw, "fwd_sha256_matches_oracle_fixture": pin}
-        dev.free(dx)
-        dev.free(dy)
     # ---- Merkle commit -----------------------------------------------------------------------------
     logn = 20 if quick else 24
     n = 1 << logn
@@ -283,11 +251,10 @@ def extras(dev, quick):
     for logsteps, bsz in ([(12, 4)] if quick else [(14, 1), (16, 1), (20, 1)]):
         steps, ext, width = 1 << logsteps, 8, 2
         plen = _stark.proof_len(steps, ext, width, degree)
-        dw0, dw, di, dp = dev.alloc(64 * steps * bsz), dev.alloc(64 * steps * bsz), dev.alloc(64 * bsz), dev.alloc(plen * bsz)
-        dev.ck(L.sh_dev_fill_mimc_units(ctx, dw0, di, steps, 0, bsz, 42), "units")
+        dw, di, dp = dev.alloc(64 * steps * bsz), dev.alloc(64 * bsz), dev.alloc(plen * bsz)
+        dev.ck(L.sh_dev_fill_mimc_units(ctx, dw, di, steps, 0, bsz, 42), "units")
         best = None
-        for _ in range(4):  # the prover consumes its witness: restore it (untimed) before every timed call
-            dev.ck(L.sh_dev_copy(ctx, dw0, dw, 64 * steps * bsz), "copy")
+        for _ in range(4):  # the prover leaves its witness intact: best of four calls on the same buffers
             dev.sync()
             dev.ck(L.sh_timer_start(ctx), "timer")
             dev.ck(L.sh_dev_stark_prove(ctx, dw, di, steps, ext, width, coefs, exps, counts, 80, bsz, dp), "stark")
@@ -300,21 +267,33 @@ def extras(dev, quick):
         out["stark_prove_batch%d_steps_2^%d" % (bsz, logsteps)] = {
             "ms_per_batch": round(best, 4), "ms_per_proof": round(best / bsz, 5), "proofs_per_s": bsz / best * 1e3,
             "proof_bytes": plen, "m_root": head.raw[:32].hex()}
-        for p_ in (dw0, dw, di, dp):
+        for p_ in (dw, di, dp):
             dev.free(p_)
     return out
 
 
+CPU_WHOLE_MAX_LOG = 21  # oracle/oracle.c: a 2^21-point forward + inverse pair takes ~17 s on one core, 2^24 ~4 min
+
+
 def cpu_baseline(logn, vectors, budget_s=10.0):
-    """The C oracle (the reference's algorithm, scalar code) on the same workload: the step's independent vectors are
-    spread over host cores, one child process per vector (oracle/cpu_worker.py), at most the cores this box gives us."""
+    """The C oracle (the reference's algorithm, scalar code) on a bounded sample of the same workload, one child process
+    per host core (oracle/cpu_worker.py), at most the cores this box gives us.  Transforms up to 2^21 points run whole,
+    one of the step's vectors per core.  A longer transform is sampled through the reference's own recursion
+    (fft.py:303-314: a 2^k-point transform = two 2^(k-1)-point transforms of the even / odd inputs + one combining level):
+    each core runs one of the 2^(k-21) branches of depth k - 21, i.e. a 2^21-point transform of x[o::2^(k-21)]; the rate
+    is scaled by 21/k for the combining levels the sample does not contain."""
     from oracle import coracle
     coracle.build()  # once, before the workers race for it
     n = 1 << logn
-    cores = max(1, min(vectors, os.cpu_count() or 1, 16))
+    sub = min(logn, CPU_WHOLE_MAX_LOG)
+    log_stride = logn - sub
+    cores = max(1, min(vectors << log_stride, os.cpu_count() or 1, 16))
     t0 = time.time()
-    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(logn), str(b), str(budget_s)], cwd=ROOT,
-                              stdout=subprocess.PIPE) for b in range(cores)]
+    if log_stride == 0:
+        cmds = [[str(sub), str(b), str(budget_s)] for b in range(cores)]
+    else:
+        cmds = [[str(sub), "0", str(budget_s), str(log_stride), str(o)] for o in range(cores)]
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker"] + c, cwd=ROOT, stdout=subprocess.PIPE) for c in cmds]
     res = []
     for pr in procs:
         out, _ = pr.communicate()
@@ -322,12 +301,20 @@ def cpu_baseline(logn, vectors, budget_s=10.0):
             raise RuntimeError("cpu_baseline worker failed")
         res.append(json.loads(out.decode().strip().splitlines()[-1]))
     wall = time.time() - t0
-    rate = sum(2 * n * r["reps"] / r["seconds"] for r in res)  # the workers run concurrently for their whole window
-    return {"value": rate, "unit": "elements/s", "cores": cores, "kind": "port",
-            "sample": "%d of the step's %d vectors, one per core; %s forward+inverse 2^%d NTTs each with oracle/oracle.c "
-                      "(%.1f s per worker, %.1f s wall)" % (cores, vectors, "/".join(str(r["reps"]) for r in res), logn,
-                                                            max(r["seconds"] for r in res), wall),
-            "roundtrip_ok": all(r["roundtrip_ok"] for r in res), "digest": res[0]["fwd_sha256"]}
+    # the workers run concurrently for their whole window
+    rate = sum(2 * (1 << sub) * r["reps"] / r["seconds"] for r in res) * sub / logn
+    if log_stride == 0:
+        sample = ("%d of the step's %d vectors, one per core; %s forward+inverse 2^%d NTTs each with oracle/oracle.c "
+                  "(%.1f s per worker, %.1f s wall)" % (cores, vectors, "/".join(str(r["reps"]) for r in res), logn,
+                                                        max(r["seconds"] for r in res), wall))
+    else:
+        sample = ("%d of the %d depth-%d branches of the reference's recursion on the 2^%d-point vector (2^%d-point forward + "
+                  "inverse transforms of x[o::%d], o = 0..%d, one per core, oracle/oracle.c; %s pairs, %.1f s per worker, "
+                  "%.1f s wall); elements/s of the sample x %d/%d for the %d combining levels it leaves out" %
+                  (cores, 1 << log_stride, log_stride, logn, sub, 1 << log_stride, cores - 1,
+                   "/".join(str(r["reps"]) for r in res), max(r["seconds"] for r in res), wall, sub, logn, log_stride))
+    return {"value": rate, "unit": "elements/s", "cores": cores, "kind": "port", "sample": sample,
+            "roundtrip_ok": all(r["roundtrip_ok"] for r in res), "digest": res[0]["fwd_sha256"] if log_stride == 0 else None}
 
 
 def cpu_baseline_c5(steps, ext=8):
@@ -382,9 +369,13 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     from starks_amd.batch import shard
     if world > 1:
-        dist.init_process_group(backend="gloo")
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=args.dist_timeout))
     mine = shard(args.units, rank, world)
     t0 = time.perf_counter()
+    if args.fail_rank == rank:
+        # what an invalid witness does to a real rank (STARK.mk_proof / sh_stark_status raise before the header exchange): the
+        # rank dies, the launcher (torch.distributed.run) ends the others and returns non-zero -- nobody waits in a collective
+        raise RuntimeError("rank %d: injected failure before the header all_gather" % rank)
     local = [hashlib.sha256(b"unit-%d" % j).digest() * 2 for j in mine]  # stand-in headers
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
@@ -405,12 +396,12 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 50 for ntt, 2 for c5)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 5 for ntt, 1 for c5)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 for ntt, 2 for c5)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3 for ntt, 1 for c5)")
     ap.add_argument("--workload", choices=["ntt", "c5"], default="ntt")
-    ap.add_argument("--logn", type=int, default=20, help="ntt: log2 transform length (configs[1] = 20)")
-    ap.add_argument("--batch", type=int, default=8, help="ntt: independent vectors transformed per step (the columns of a "
-                    "trace: one launch sequence covers all of them)")
+    ap.add_argument("--logn", type=int, default=24, help="ntt: log2 transform length (configs[3] = 24, configs[1] = 20)")
+    ap.add_argument("--batch", type=int, default=1, help="ntt: independent vectors transformed per step (e.g. the columns "
+                    "of a trace: one launch sequence covers all of them)")
     ap.add_argument("--units", type=int, default=None, help="c5: proofs in the batch (512; 16 with --quick)")
     ap.add_argument("--logsteps", type=int, default=None, help="c5: log2 trace length (16; 10 with --quick)")
     ap.add_argument("--chunk", type=int, default=128, help="c5: proofs per batched launch")
@@ -422,13 +413,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                     "the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--dist-timeout", type=float, default=900.0, help="seconds a collective may wait for the other ranks")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="--dry-run only: this rank raises before the header exchange "
+                    "(the launcher must exit non-zero, not hang)")
     ap.add_argument("--dry-run", action="store_true", help="CPU tests: launcher, sharding and gather only -- no GPU work, "
                     "value = null")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 50 if args.workload == "ntt" else 2
+        args.steps = 20 if args.workload == "ntt" else 2
     if args.warmup is None:
-        args.warmup = 5 if args.workload == "ntt" else 1
+        args.warmup = 3 if args.workload == "ntt" else 1
     if args.units is None:
         args.units = 16 if args.quick else 512
     if args.logsteps is None:
@@ -462,9 +456,10 @@ def main():
     use_dist = world > 1 or (os.environ.get("BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if use_dist:
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index),
+                                    timeout=datetime.timedelta(seconds=args.dist_timeout))
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=datetime.timedelta(seconds=args.dist_timeout))
 
     dev = Dev()
     L, ctx = dev.L, dev.ctx
@@ -524,9 +519,11 @@ def main():
         res = run_c5(args.steps, args.warmup)
         steps = 1 << args.logsteps
         n = steps * 8
-        # algorithmic bytes of one proof (SURVEY 8(d) per-unit figures): per column LDE 64 (s + N) + 64 s, quotients /
-        # leaves / combination read and write each evaluation array once more, FRI 203 N
-        alg = 2 * (64.0 * (2 * steps + n)) + (96.0 * 2 + 64.0 * 2 + 96.0 * 2 + 96.0 * 2 + 32.0) * n + (203.0 - 64.0) * n
+        # SURVEY 8(d) gives per-unit bytes for the NTT (64 B per element per transform) and the FRI commit (203 B per domain
+        # point) only: per proof, two columns x (inverse NTT_s, NTT_N for P, NTT_s for Q) + one FRI commit whose round-0 NTT
+        # the prover does not need (l is built on evaluations).  The quotient / packed-leaf / combination kernels have no
+        # 8(d) figure and are left out: `achieved` is a lower bound of the bytes the proof moves.
+        alg = 2 * 64.0 * (2 * steps + n) + (203.0 - 64.0) * n
         achieved = alg * len(shard(args.units, rank, world)) / (res["rank0_event_ms_per_step"] * 1e-3) / 1e9
         line = {
             "metric": "stark_proofs_per_sec", "value": res["proofs_per_s"], "unit": "proofs/s", "n_gpus": world,
@@ -542,7 +539,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "whole proof (NTT passes ~30 %, packed-leaf hashing ~18 %, quotients ~20 %: DESIGN.md section 5)",
                          "algorithmic_bytes_per_proof": alg,
-                         "note": "integer-VALU / BLAKE2s-ALU bound, not HBM bound"},
+                         "note": "SURVEY 8(d) bytes of the proof's transforms and FRI commit only (the quotient, packed-leaf and "
+                                 "combination kernels have no 8(d) figure); integer-VALU / BLAKE2s-ALU bound, not HBM bound"},
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_c5(steps)
@@ -576,22 +574,31 @@ def main():
     fence()
     dt_max = max_over_ranks(time.perf_counter() - t0)
 
-    # correctness of what was timed: x == invNTT(NTT(x)) and the forward digest against the fixture (rank 0)
-    a, b = ctypes.create_string_buffer(32 * n * B), ctypes.create_string_buffer(32 * n * B)
-    dev.ck(L.sh_dev_to_wire(ctx, dx, a, n * B), "dl")
-    dev.ck(L.sh_dev_to_wire(ctx, dy, b, n * B), "dl")
-    roundtrip_ok = a.raw == b.raw
+    # correctness of what was timed: x == invNTT(NTT(x)) on every element, and the forward digest of vector 0 against the
+    # committed fixture (rank 0): reference-generated up to 2^20 (tests/golden/ntt.json), the pinned C oracle's above
+    # (tests/golden/ntt_large.json)
+    CH = min(n * B, 1 << 20)
+    a, b = ctypes.create_string_buffer(32 * CH), ctypes.create_string_buffer(32 * CH)
+    roundtrip_ok = True
+    for off in range(0, n * B, CH):
+        dev.ck(L.sh_dev_to_wire(ctx, ctypes.c_void_p(dx.value + 32 * off), a, CH), "dl")
+        dev.ck(L.sh_dev_to_wire(ctx, ctypes.c_void_p(dy.value + 32 * off), b, CH), "dl")
+        roundtrip_ok = roundtrip_ok and a.raw == b.raw
     dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, B, w, 0), "ntt")
-    dev.ck(L.sh_dev_to_wire(ctx, dy, b, n), "dl")
-    fwd_digest = hashlib.sha256(b.raw[:32 * n]).hexdigest()  # vector 0
-    golden_ok = None
-    try:
-        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ntt.json")))
-        hit = [c for c in gold["cases"] if c["n"] == n and c["n_in"] == n]
-        if hit and rank == 0:
-            golden_ok = hit[0]["sha_fwd"] == fwd_digest
-    except Exception:
-        pass
+    h = hashlib.sha256()
+    for off in range(0, n, CH):  # vector 0
+        dev.ck(L.sh_dev_to_wire(ctx, ctypes.c_void_p(dy.value + 32 * off), b, min(CH, n)), "dl")
+        h.update(b.raw[:32 * min(CH, n)])
+    fwd_digest = h.hexdigest()
+    golden_ok, golden_src = None, None
+    for gf in ("ntt.json", "ntt_large.json"):
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", gf)))
+            hit = [c for c in gold["cases"] if c["n"] == n and c.get("n_in", n) == n]
+            if hit and rank == 0:
+                golden_ok, golden_src = hit[0]["sha_fwd"] == fwd_digest, "tests/golden/" + gf
+        except Exception:
+            pass
     ok = all_ok(roundtrip_ok and golden_ok is not False)  # the only exchange: a 1-word status gather over RCCL
 
     elems_per_step = 2 * n * B
@@ -599,8 +606,8 @@ def main():
     alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
     achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
     traffic, traffic_src = None, None
-    for tf in ("r02_traffic_2p%d.json" % args.logn, "r01_traffic.json"):
-        try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_r02.sh)
+    for tf in ("r03_traffic_2p%d.json" % args.logn, "r02_traffic_2p%d.json" % args.logn):
+        try:  # HBM bytes per launch from the committed PMC run of this same command (tools/prof_r03.sh)
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if tj.get("logn", 20) == args.logn and tj.get("vectors_per_step", 1) == B:
                 traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
@@ -609,34 +616,54 @@ def main():
         except Exception:
             pass
     passes = int(L.sh_ntt_passes(n, B))
+    path = L.sh_ntt_path_name().decode()
+    cfg = {20: "configs[1]", 24: "configs[3]"}.get(args.logn, "2^%d" % args.logn)
     line = {
         "metric": "ntt_field_elements_per_sec", "value": value, "unit": "elements/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU%s)" %
+        (" + i8 MFMA twiddle products" if path == "mfma" else ""),
         "data": "synthetic", "config": {
-            "workload": "configs[1]: 2^%d-point NTT + inverse NTT over the MiMC prime, %d independent vectors per step "
-                        "per GPU (the columns of a trace, one launch sequence), x == invNTT(NTT(x)) checked on all; "
-                        "the single-vector figure is single_vector_elements_per_s" % (args.logn, B),
+            "workload": "%s: 2^%d-point NTT + inverse NTT over the MiMC prime, %d vector%s per step per GPU, resident in "
+                        "HBM; x == invNTT(NTT(x)) checked on every element and the forward digest against the committed "
+                        "fixture" % (cfg, args.logn, B, "" if B == 1 else "s (independent, one launch sequence)"),
             "n": n, "vectors_per_step": B, "elements_per_step": elems_per_step,
             "parallelism": "independent vectors x%d" % world},
         "field_mul_eq_per_s": (n // 2) * args.logn * 2 * B * args.steps * world / dt_max,
-        "check": {"roundtrip_ok": ok, "fwd_sha256": fwd_digest, "matches_reference_fixture": golden_ok},
+        "check": {"roundtrip_ok": ok, "fwd_sha256": fwd_digest, "matches_fixture": golden_ok, "fixture": golden_src},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 64.0 * n * B / passes,
-                     "kernel": "ntt_pass_kernel (%d launches per 2^%d transform)" % (passes, args.logn),
+                     "kernel": "%s (%d launches per 2^%d transform; all passes of both directions averaged)" %
+                               ("ntt_ctile_kernel" if path == "mfma" else "ntt_pass_kernel", passes, args.logn),
                      "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
                      "note": "integer-VALU bound, not HBM bound; see DESIGN.md section 5"},
     }
-    single_ms = None
     if rank == 0 and world == 1 and not args.no_single:
-        # the literal configs[1]: the same transform pair on ONE vector (a launch's load / store phases are then exposed)
-        single_ms = dev.timed(lambda: (dev.ck(L.sh_dev_ntt(ctx, dx, dy, n, 1, w, 0), "ntt"),
-                                       dev.ck(L.sh_dev_ntt(ctx, dy, dy, n, 1, w, 1), "intt")), 50)
-        line["single_vector_elements_per_s"] = 2 * n / single_ms * 1e3
-        line["single_vector_ms_per_fwd_inv"] = round(single_ms, 5)
-        if B >= 2 and B % 2 == 0:
+        # the other shapes of the metric: configs[1] literally (ONE 2^20-point pair: a launch's load / store phases are
+        # exposed) and 8 independent 2^20-point vectors per launch sequence (the columns of a trace)
+        n20 = 1 << (14 if args.quick else 20)
+        w20 = root_of(n20).to_bytes(32, "big")
+        sx, sy = dev.alloc(32 * n20 * 8), dev.alloc(32 * n20 * 8)
+        dev.ck(L.sh_dev_fill_seeded(ctx, sx, n20 * 8, 0x5eed), "fill")
+        for vecs, key in ((1, "single_vector"), (8, "ntt_2^%d_x8" % (n20.bit_length() - 1))):
+            ms = dev.timed(lambda: (dev.ck(L.sh_dev_ntt(ctx, sx, sy, n20, vecs, w20, 0), "ntt"),
+                                    dev.ck(L.sh_dev_ntt(ctx, sy, sy, n20, vecs, w20, 1), "intt")), 50)
+            line[key + "_elements_per_s"] = 2 * n20 * vecs / ms * 1e3
+            line[key + "_ms_per_fwd_inv"] = round(ms, 5)
+            line[key + "_hbm_frac"] = 64.0 * 2 * n20 * vecs / ms / 1e6 / HBM_PEAK_GBS
+        s1, s2 = ctypes.create_string_buffer(32 * n20 * 8), ctypes.create_string_buffer(32 * n20 * 8)
+        dev.ck(L.sh_dev_to_wire(ctx, sx, s1, n20 * 8), "dl")
+        dev.ck(L.sh_dev_to_wire(ctx, sy, s2, n20 * 8), "dl")
+        line["check"]["secondary_roundtrip_ok"] = s1.raw == s2.raw
+        del s1, s2
+        dev.free(sx)
+        dev.free(sy)
+        if B >= 2 and B % 2 == 0 and n * B <= (1 << 23):
+            a = ctypes.create_string_buffer(32 * n * B)
+            b = ctypes.create_string_buffer(32 * n * B)
+            dev.ck(L.sh_dev_to_wire(ctx, dx, a, n * B), "dl")
             # The same step with its vectors split over TWO contexts (= two streams), free-running: the launches of one
             # stream fill the ramps and tails of the other's.  Reported beside `value`, never as `value`: with two kernels
             # resident at once a per-launch duration no longer maps to a per-launch byte count.
@@ -679,17 +706,14 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.logn, B)
-            line["cpu_baseline"]["digest_matches_gpu"] = line["cpu_baseline"].pop("digest") == fwd_digest
+            dg = line["cpu_baseline"].pop("digest")
+            line["cpu_baseline"]["digest_matches_gpu"] = None if dg is None else dg == fwd_digest
         if not args.no_extras:
             line["extra"] = extras(dev, args.quick)
             k20 = "fri_commit_steps_2^20"
             if k20 in line["extra"]:
                 line["fri_commit_ms_2^20_trace"] = line["extra"][k20]["ms"]
             line["fri_commit_ms_2^14_trace"] = line["extra"]["fri_commit_steps_2^14"]["ms"]
-            big = [k for k in line["extra"] if k.startswith("ntt_2^")]
-            if big:
-                line["ntt_large_elements_per_s"] = line["extra"][big[0]]["elements_per_s"]
-                line["ntt_large_hbm_frac"] = line["extra"][big[0]]["hbm_frac"]
     if rank == 0:
         emit(line)
     if use_dist:

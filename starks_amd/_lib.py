@@ -76,6 +76,7 @@ def lib():
         "sh_host_alloc": (i32, [c_p, u64, pp]),
         "sh_host_free": (i32, [c_p, c_p]),
         "sh_ntt_passes": (u32, [u64, u32]),
+        "sh_ntt_path_name": (ctypes.c_char_p, []),
         "sh_dev_download_2d": (i32, [c_p, c_p, u64, c_p, u64, u64]),
         "sh_dev_fill_seeded": (i32, [c_p, c_p, u64, u64]),
         "sh_dev_ntt": (i32, [c_p, c_p, c_p, u64, u32, u8p, i32]),
@@ -89,6 +90,8 @@ def lib():
         "sh_stark_status": (i32, [c_p]),
         "sh_stark_status_batch": (i32, [c_p, c_p, u32]),
         "sh_ctx_trim": (i32, [c_p]),
+        "sh_ctx_set_plan_budget": (i32, [c_p, u64]),
+        "sh_ctx_stats": (i32, [c_p, ctypes.POINTER(u64)]),
         "sh_dev_fill_mimc_units": (i32, [c_p, c_p, c_p, u64, u32, u32, u32]),
     }
     for name, (res, args) in sig.items():
@@ -156,9 +159,11 @@ class PinnedBuffer(object):
         self.view = (ctypes.c_char * nbytes).from_address(self.ptr.value)
 
     def close(self):
-        if self.ptr:
-            lib().sh_host_free(ctx(), self.ptr)
-            self.ptr = None
+        """Frees the buffer; `view` is dropped with it.  After `_lib.close()` the context (and with it every pinned
+        allocation's owner) is gone: nothing is re-created here just to free."""
+        ptr, self.ptr, self.view = self.ptr, None, None
+        if ptr and _ctx is not None:
+            check(lib().sh_host_free(_ctx, ptr), "sh_host_free")
 
     def __del__(self):  # pragma: no cover
         try:
@@ -171,20 +176,23 @@ def to_wire(values, modulus=MIMC_P):
     """list of ints / field elements -> concatenated 32-byte big-endian strings (modp.py:94-95).
 
     Values already in [0, 2^256) are sent as they are (an element built from bytes may be unreduced,
-    modp.py:33-34; the device reduces); anything else is reduced first, as `field(int)` would."""
-    out = bytearray(32 * len(values))
+    modp.py:33-34; the device reduces); anything else is reduced first, as `field(int)` would.
+
+    One C-level `int.to_bytes` per value and one join (0.3 us per value; the per-value slice assignment this replaces
+    took twice that); plain ints in range -- the common case -- take the first branch without any per-value test."""
+    try:
+        return b"".join([v.to_bytes(32, "big") for v in values])
+    except (AttributeError, OverflowError, TypeError):
+        pass  # field elements (no int.to_bytes signature), negative or >= 2^256 values: the general path
     lim = 1 << 256
-    for i, v in enumerate(values):
-        x = int(v)
-        if not 0 <= x < lim:
-            x %= modulus
-        out[32 * i:32 * i + 32] = x.to_bytes(32, "big")
-    return bytes(out)
+    ints = [int(v) for v in values]
+    return b"".join([(x if 0 <= x < lim else x % modulus).to_bytes(32, "big") for x in ints])
 
 
 def from_wire(buf):
-    mv = memoryview(buf)
-    return [int.from_bytes(mv[i:i + 32], "big") for i in range(0, len(mv), 32)]
+    """concatenated 32-byte big-endian strings -> list of ints (0.17 us per value)."""
+    mv, conv = memoryview(buf), int.from_bytes
+    return [conv(mv[i:i + 32], "big") for i in range(0, len(mv), 32)]
 
 
 def order_of_root(root, modulus=MIMC_P):

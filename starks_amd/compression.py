@@ -36,34 +36,33 @@ def compress_fri(prf):
     return out
 
 
+def _tokens(stream):
+    """The stream with every 2-byte back-reference replaced by the object it points at."""
+    for x in stream:
+        yield stream[int.from_bytes(x, "big")] if len(x) == 2 else x
+
+
 def decompress_fri(proof):
-    """compression.py:35-64"""
-
-    def get(pos):
-        x = proof[pos]
-        return proof[int.from_bytes(x, "big")] if len(x) == 2 else x
-
-    o, pos = [], 0
-    while proof[pos] != _MARK["final"]:
-        assert get(pos) == _MARK["item"]
-        root = get(pos + 1)
-        pos += 2
-        yproofs = []
-        while get(pos) not in (_MARK["item"], _MARK["final"]):
-            yproof = []
-            while get(pos) != _MARK["sample"]:
-                branch = []
-                while get(pos) != _MARK["branch"]:
-                    branch.append(get(pos))
-                    pos += 1
-                yproof.append(branch)
-                pos += 1
-            yproofs.append(yproof)
-            pos += 1
-        o.append([root, yproofs])
-    pos += 1
-    o.append([get(x) for x in range(pos, len(proof))])
-    return o
+    """Inverse of compress_fri (format: compression.py:35-64), as one pass over the resolved tokens: a marker closes
+    whatever list is open at its level, anything else is a node of the open branch (or the root right after an item
+    marker); everything behind the final marker is the last layer's values."""
+    layers, tok = [], _tokens(proof)
+    sample, branch = [], []
+    for x in tok:
+        if x == _MARK["final"]:
+            break
+        if x == _MARK["item"]:
+            layers.append([next(tok), []])
+        elif x == _MARK["branch"]:
+            sample.append(branch)
+            branch = []
+        elif x == _MARK["sample"]:
+            layers[-1][1].append(sample)
+            sample = []
+        else:
+            branch.append(x)
+    layers.append(list(tok))
+    return layers
 
 
 def compress_branches(branches):
@@ -78,21 +77,19 @@ def compress_branches(branches):
 
 
 def decompress_branches(proof):
-    """compression.py:85-101"""
-
-    def get(pos):
-        x = proof[pos]
-        return proof[int.from_bytes(x, "big")] if len(x) == 2 else x
-
-    o, pos = [], 0
-    while pos < len(proof):
-        branch = []
-        while pos < len(proof) and get(pos) != _MARK["item"]:
-            branch.append(get(pos))
-            pos += 1
-        o.append(branch)
-        pos += 1
-    return o
+    """Inverse of compress_branches (format: compression.py:85-101): an item marker closes a branch; like the
+    reference, a stream that does not end on a marker yields its open branch as the last one."""
+    branches, branch, closed = [], [], True
+    for x in _tokens(proof):
+        closed = x == _MARK["item"]
+        if closed:
+            branches.append(branch)
+            branch = []
+        else:
+            branch.append(x)
+    if not closed:
+        branches.append(branch)
+    return branches
 
 
 def proof_bytes(c):

@@ -86,6 +86,8 @@ struct NttPlan {
   PowTable base;             // unscaled table of root (sh_power_cycle, FRI fold)
   fp* scale = nullptr;       // n^-1 on the device (one-pass scaled plans)
   std::vector<void*> owned;  // device allocations to free
+  size_t bytes = 0;          // sum of the owned allocations (plan-cache budget)
+  uint64_t last_use = 0;     // ctx tick of the most recent lookup (LRU eviction)
 };
 
 }  // namespace
@@ -96,6 +98,10 @@ struct sh_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   std::map<std::string, NttPlan*> plans;
+  // plan cache accounting: least-recently-used plans are evicted on entry of a public call once the tables held exceed
+  // the byte budget (STARKHIP_PLAN_CACHE_MB, default 16 GiB of the 288 GB) or the plan count its cap
+  size_t plan_bytes = 0, plan_budget = (size_t)16 << 30;
+  uint64_t tick = 0, plans_built = 0, plans_evicted = 0;
   enum {
     WS_WIRE = 0, WS_X, WS_Y, WS_NTT, WS_TREE_A, WS_TREE_B, WS_COL_A, WS_COL_B, WS_MISC, WS_PROOF,
     WS_ST_TRACE, WS_ST_P, WS_ST_D, WS_ST_B, WS_ST_Q, WS_ST_SMALL, WS_ST_MTREE, WS_COUNT
@@ -182,15 +188,18 @@ bool host_is_pinned(const void* h) {
   return at.type == hipMemoryTypeHost;
 }
 
-// host (pageable) -> device through the pinned slots: the host memcpy of chunk i+1 overlaps the DMA of chunk i.
-// Returns once `h` has been consumed; the device copy completes in stream order.
-int h2d(sh_ctx* c, void* d, const void* h, size_t bytes) {
+// host -> device on the ctx stream.  Pageable sources go through the pinned slots (the host memcpy of chunk i+1 overlaps
+// the DMA of chunk i) and have been consumed when this returns.  A PINNED source of 64 KiB or more is handed to the DMA
+// engine as it is and is read in stream order, i.e. possibly AFTER this returns: the caller must not reuse or free it
+// before the stream has passed the copy (every entry point that takes caller buffers synchronises before it returns).
+// `staged`: always go through the pinned slots, whatever the size (sources that die right after the call: plan tables).
+int h2d(sh_ctx* c, void* d, const void* h, size_t bytes, bool staged = false) {
   if (bytes == 0) return SH_OK;
-  if (bytes >= ((size_t)64 << 10) && host_is_pinned(h)) {
+  if (!staged && bytes >= ((size_t)64 << 10) && host_is_pinned(h)) {
     HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     return SH_OK;
   }
-  if (bytes < ((size_t)64 << 10)) {
+  if (!staged && bytes < ((size_t)64 << 10)) {
     HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     return SH_OK;
   }
@@ -240,11 +249,24 @@ int d2h(sh_ctx* c, void* h, const void* d, size_t bytes) {
   return SH_OK;
 }
 
+// device allocation owned by (and accounted to) a plan
+int plan_alloc(sh_ctx* c, NttPlan* pl, size_t bytes, void** out) {
+  void* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, bytes ? bytes : 32));
+  pl->owned.push_back(d);
+  pl->bytes += bytes;
+  *out = d;
+  return SH_OK;
+}
+// host table -> device, in stream order (no device-wide synchronisation: the host vector is pageable, so h2d has
+// consumed it on return, and every reader of the table is a later launch on the same stream)
+int upload_bytes(sh_ctx* c, NttPlan* pl, const void* host, size_t bytes, void** dev) {
+  SH_TRY(plan_alloc(c, pl, bytes, dev));
+  return h2d(c, *dev, host, bytes, true);
+}
 int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) {
   void* d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, host.size() * sizeof(fp)));
-  pl->owned.push_back(d);
-  HIP_TRY(c, hipMemcpy(d, host.data(), host.size() * sizeof(fp), hipMemcpyHostToDevice));
+  SH_TRY(upload_bytes(c, pl, host.data(), host.size() * sizeof(fp), &d));
   *dev = reinterpret_cast<fp*>(d);
   return SH_OK;
 }
@@ -303,21 +325,13 @@ int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp
     out->lb = (uint32_t)lb;
     return SH_OK;
   }
-  // expand on the device: full[e] = lo[e & mask] * hi[e >> lb]
-  void *dlo = nullptr, *dhi = nullptr, *full = nullptr;
-  HIP_TRY(c, hipMalloc(&full, sizeof(fp) << log_order));
-  pl->owned.push_back(full);
-  hipError_t e = hipMalloc(&dlo, lo.size() * sizeof(fp));
-  if (e == hipSuccess) e = hipMalloc(&dhi, hi.size() * sizeof(fp));
-  if (e == hipSuccess) e = hipMemcpy(dlo, lo.data(), lo.size() * sizeof(fp), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dhi, hi.data(), hi.size() * sizeof(fp), hipMemcpyHostToDevice);
-  if (e == hipSuccess)
-    e = shk_powers(reinterpret_cast<fp*>(dlo), reinterpret_cast<fp*>(dhi), (uint32_t)lb, reinterpret_cast<fp*>(full),
-                   (uint64_t)1 << log_order, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (dlo) (void)hipFree(dlo);
-  if (dhi) (void)hipFree(dhi);
-  HIP_TRY(c, e);
+  // expand on the device, in stream order: full[e] = lo[e & mask] * hi[e >> lb] (the two small halves stay with the plan)
+  void* full = nullptr;
+  fp *dlo = nullptr, *dhi = nullptr;
+  SH_TRY(plan_alloc(c, pl, sizeof(fp) << log_order, &full));
+  SH_TRY(upload_table(c, pl, lo, &dlo));
+  SH_TRY(upload_table(c, pl, hi, &dhi));
+  HIP_TRY(c, shk_powers(dlo, dhi, (uint32_t)lb, reinterpret_cast<fp*>(full), (uint64_t)1 << log_order, c->stream));
   out->lo = reinterpret_cast<fp*>(full);
   out->hi = nullptr;
   out->lb = (uint32_t)log_order;
@@ -368,17 +382,21 @@ void choose_radices(int log_n, bool few, std::vector<int>* out) {
   for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));
 }
 
-constexpr size_t MAX_PLANS = 96;  // twiddle-table sets kept per ctx before the caches are dropped (sh_ctx_trim)
+constexpr size_t MAX_PLANS = 1024;  // count cap of the plan cache (the byte budget normally binds first)
+
+void free_plan(sh_ctx* c, NttPlan* pl) {
+  for (void* p : pl->owned) (void)hipFree(p);
+  c->plan_bytes -= pl->bytes <= c->plan_bytes ? pl->bytes : c->plan_bytes;
+  delete pl;
+}
 
 // Free every cached table (NTT plans, the STARK prover's inverse tables) and the workspaces, after the stream drained.
 // Everything is rebuilt on demand.
 int trim(sh_ctx* c) {
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  for (auto& kv : c->plans) {
-    for (void* p : kv.second->owned) (void)hipFree(p);
-    delete kv.second;
-  }
+  for (auto& kv : c->plans) free_plan(c, kv.second);
   c->plans.clear();
+  c->plan_bytes = 0;
   for (auto& kv : c->inv_z2) (void)hipFree(kv.second);
   c->inv_z2.clear();
   for (auto& kv : c->inv_omega) (void)hipFree(kv.second);
@@ -391,12 +409,31 @@ int trim(sh_ctx* c) {
   return SH_OK;
 }
 
+// Least-recently-used plans go until the cache is inside its byte budget and count cap again; plans looked up recently
+// (a prover's hot shapes) stay.  One stream synchronisation if anything is evicted (queued launches may read the tables).
+int evict_plans(sh_ctx* c) {
+  bool synced = false;
+  while (!c->plans.empty() && (c->plan_bytes > c->plan_budget || c->plans.size() + 4 > MAX_PLANS)) {
+    auto victim = c->plans.begin();
+    for (auto it = c->plans.begin(); it != c->plans.end(); ++it)
+      if (it->second->last_use < victim->second->last_use) victim = it;
+    if (!synced) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      synced = true;
+    }
+    free_plan(c, victim->second);
+    c->plans.erase(victim);
+    ++c->plans_evicted;
+  }
+  return SH_OK;
+}
+
 // Called on entry of every public function that builds plans, never while a plan pointer is held: a long-lived prover
-// that meets many shapes must not grow for ever (a call creates at most 4 plans).
+// that meets many shapes must not grow for ever (a call creates at most 4 plans, so the budget can be overshot by one
+// call's tables until the next entry).
 int enter(sh_ctx* c) {
   HIP_TRY(c, hipSetDevice(c->device));
-  if (c->plans.size() + 4 > MAX_PLANS) SH_TRY(trim(c));
-  return SH_OK;
+  return evict_plans(c);
 }
 
 std::string plan_key(const fp& root, uint64_t n, bool scaled) {
@@ -429,10 +466,23 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
   const std::string key = plan_key(root_eff, n, scaled) + ((radix != other && few) ? "f" : "");
   auto it = c->plans.find(key);
   if (it != c->plans.end()) {
+    it->second->last_use = ++c->tick;
     *out = it->second;
     return SH_OK;
   }
+  // every exit before the plan is registered (error codes AND the early returns of HIP_TRY / SH_TRY) frees what was built
+  struct Guard {
+    sh_ctx* c;
+    NttPlan* p;
+    ~Guard() {
+      if (p) {
+        for (void* d : p->owned) (void)hipFree(d);
+        delete p;
+      }
+    }
+  } guard{c, nullptr};
   NttPlan* pl = new NttPlan();
+  guard.p = pl;
   pl->n = n;
   pl->log_n = ilog2(n);
   pl->scaled = scaled;
@@ -465,16 +515,13 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         rc = upload_table(c, pl, pairs, &dev);
         wr_by_radix[r] = reinterpret_cast<const fp2*>(dev);
         mats_by_radix[r] = nullptr;
-        if (rc == SH_OK && r >= 5 && r <= 8) {  // operand images for the matrix-core butterflies (ntt_mfma.hip)
+        // operand images for the matrix-core butterflies (ntt_mfma.hip), only when those passes are selected
+        if (rc == SH_OK && r >= 5 && r <= 8 && use_mfma_path()) {
           std::vector<TwMat> mm(t.size());
           for (size_t i = 0; i < t.size(); ++i)
             if (!shk_build_twmat(t[i], &mm[i])) rc = SH_ERR_INVALID;
           void* d = nullptr;
-          if (rc == SH_OK) {
-            HIP_TRY(c, hipMalloc(&d, mm.size() * sizeof(TwMat)));
-            pl->owned.push_back(d);
-            HIP_TRY(c, hipMemcpy(d, mm.data(), mm.size() * sizeof(TwMat), hipMemcpyHostToDevice));
-          }
+          if (rc == SH_OK) rc = upload_bytes(c, pl, mm.data(), mm.size() * sizeof(TwMat), &d);
           mats_by_radix[r] = d;
         }
       }
@@ -496,12 +543,15 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         fp* tw2 = nullptr;
         const int log_S = pl->log_n - log_P - r;
         if (rc == SH_OK && r + log_S <= tw2_max_log()) {
+          // a failed allocation of the row table (up to 256 MiB) is not fatal: the pass keeps the power-table lookup
           void* dv = nullptr;
-          HIP_TRY(c, hipMalloc(&dv, sizeof(fp) << (r + log_S)));
-          pl->owned.push_back(dv);
-          tw2 = reinterpret_cast<fp*>(dv);
-          HIP_TRY(c, shk_tw2(t.lo, t.hi, t.lb, tw2, (uint32_t)r, (uint32_t)log_S, c->stream));
-          HIP_TRY(c, hipStreamSynchronize(c->stream));
+          if (plan_alloc(c, pl, sizeof(fp) << (r + log_S), &dv) == SH_OK) {
+            tw2 = reinterpret_cast<fp*>(dv);
+            HIP_TRY(c, shk_tw2(t.lo, t.hi, t.lb, tw2, (uint32_t)r, (uint32_t)log_S, c->stream));
+          } else {
+            (void)hipGetLastError();
+            c->err.clear();
+          }
         }
         pl->tw2.push_back(tw2);
       }
@@ -512,11 +562,11 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
     std::vector<fp> s(1, ninv);
     rc = upload_table(c, pl, s, &pl->scale);
   }
-  if (rc != SH_OK) {
-    for (void* p : pl->owned) (void)hipFree(p);
-    delete pl;
-    return rc;
-  }
+  if (rc != SH_OK) return rc;  // the guard frees the partial plan
+  guard.p = nullptr;
+  pl->last_use = ++c->tick;
+  c->plan_bytes += pl->bytes;
+  ++c->plans_built;
   c->plans[key] = pl;
   *out = pl;
   return SH_OK;
@@ -835,6 +885,7 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   const uint32_t degree = c->terms_degree;
   SH_TRY(stark_check_shape(steps, ext, width, degree, samples));
   if (!d_wit || !d_inputs || !d_proof || batch == 0) return SH_ERR_INVALID;
+  if (batch > 65535) return SH_ERR_UNSUPPORTED;  // the leaf / spot-check kernels launch one grid row (blockIdx.y) per proof
   const uint64_t n = steps * ext, cols = (uint64_t)batch * width;
   if (cols > 0xffffffffull) return SH_ERR_UNSUPPORTED;
   const fp g2 = h_root_of_order_pow2(ilog2(n));           // stark.py:205
@@ -1013,6 +1064,10 @@ int sh_ctx_create(int device, sh_ctx** out) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SH_ERR_HIP;
+  }
+  if (const char* e = getenv("STARKHIP_PLAN_CACHE_MB")) {
+    const long long mb = atoll(e);
+    if (mb >= 0) c->plan_budget = (size_t)mb << 20;
   }
   *out = c;
   return SH_OK;
@@ -1370,6 +1425,8 @@ uint32_t sh_ntt_passes(uint64_t n, uint32_t batch) {
   return (uint32_t)r.size();
 }
 
+const char* sh_ntt_path_name(void) { return use_mfma_path() ? "mfma" : "valu"; }
+
 uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
   return fri_proof_len(n, maxdeg_plus_1, samples);
 }
@@ -1420,6 +1477,19 @@ int sh_ctx_trim(sh_ctx* c) {
   if (!c) return SH_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   return trim(c);
+}
+int sh_ctx_set_plan_budget(sh_ctx* c, uint64_t bytes) {
+  if (!c) return SH_ERR_INVALID;
+  c->plan_budget = (size_t)bytes;
+  return enter(c);
+}
+int sh_ctx_stats(const sh_ctx* c, uint64_t out[4]) {
+  if (!c || !out) return SH_ERR_INVALID;
+  out[0] = c->plans.size();
+  out[1] = c->plan_bytes;
+  out[2] = c->plans_built;
+  out[3] = c->plans_evicted;
+  return SH_OK;
 }
 
 int sh_dev_fill_mimc_units(sh_ctx* c, void* d_witness, void* d_inputs, uint64_t steps, uint32_t first_unit, uint32_t batch,

@@ -274,7 +274,9 @@ __global__ void __launch_bounds__(64) stark_scalars_kernel(const uint32_t* mnode
 template <int W>  // W = the width when it is 1 or 2 (all values of a point are requested before the first product), else 0
 __global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, const fp* scal, fp* l_evals, uint32_t* nodes) {
   // the proof's 3 * width scalar pairs, staged in LDS once per workgroup (kept in registers they would cost 16 VGPRs each)
-  __shared__ uint4 sc_lds[9 * 3 * 4];
+  // the 3 * width scalars as fp_mul2 pairs: 12 uint4 per trace column, one per thread of the first width * 12
+  static_assert(TPB >= SHK_STARK_MAX_WIDTH * 12, "the scalar staging needs one thread per uint4");
+  __shared__ uint4 sc_lds[SHK_STARK_MAX_WIDTH * 12];
   const uint64_t N = a.n, q = N >> 2;
   const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   const uint64_t b = blockIdx.y;

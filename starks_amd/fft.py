@@ -10,9 +10,9 @@ libstarkhip.so and raises when the library or the device is missing: there is no
 
 Inputs the device code cannot represent at all -- another modulus (the reference's unit tests use Z/31,
 test_fft.py:98-113,132-149) or a root whose order is not a power of two (n = 6 there) -- are outside the hot path; for
-those `fft_1d` follows the reference's own recursion on the host (`_host_fft_1d`, a few lines of Python on field
-elements), so that the reference's unit tests run unchanged through this module.  It is never used for the MiMC field
-with a power-of-two order.
+those `fft_1d` evaluates the transform directly on the host (`_host_dft`: Horner evaluation at every power of the
+root, O(n^2) on field elements, orders up to 2^12), so that the reference's unit tests run unchanged through this
+module.  It is never used for the MiMC field with a power-of-two order.
 """
 import ctypes
 
@@ -58,54 +58,42 @@ def _on_device(modulus, root_of_unity):
     return int(modulus) == MIMC_P and _lib.order_of_root(root_of_unity) is not None
 
 
-def _host_simple_ft(vals, roots):
-    """starks/fft.py:287-300: the naive transform the reference uses below 5 points (and for odd factors)."""
-    L = len(roots)
-    out = []
-    for i in range(L):
-        last = 0
-        for j in range(L):
-            last += vals[j] * roots[(i * j) % L]
-        out.append(last)
+_HOST_MAX_ORDER = 1 << 12
+
+
+def _host_dft(field, vals, modulus, root_of_unity, inv=False):
+    """Transform over a field / order the device code does not cover (another modulus, or an order that is not a power
+    of two -- the reference's Z/31 unit tests, test_fft.py:98-113,132-149): never the hot path, so no fast algorithm --
+    value k of the result is the input polynomial evaluated at root^k by Horner's rule (root^-k for the inverse, then
+    scaled by 1/n).  Every quantity is an exact residue, so the result equals fft_1d's (starks/fft.py:316-331) whatever
+    recursion that uses.  Element arithmetic is the field type's own."""
+    g = field(root_of_unity)
+    one = field(1)
+    order, t = 1, g
+    while t != one:
+        t = t * g
+        order += 1
+        if order > _HOST_MAX_ORDER:
+            raise NotImplementedError("host transform: root order above %d (use the MiMC field on the GPU)" % _HOST_MAX_ORDER)
+    coeffs = [field(v) for v in vals]
+    if len(coeffs) > order:
+        raise ValueError("more input values (%d) than the order of the root of unity (%d)" % (len(coeffs), order))
+    step = g ** (order - 1) if inv else g          # g^-1 = g^(order-1)
+    scale = field(order) ** (int(modulus) - 2) if inv else None
+    out, point = [], one
+    for _ in range(order):
+        acc = field(0)
+        for c in reversed(coeffs):
+            acc = acc * point + c
+        out.append(acc * scale if inv else acc)
+        point = point * step
     return out
-
-
-def _host_fft(vals, roots):
-    """starks/fft.py:303-314"""
-    if len(vals) <= 4 or len(vals) % 2:
-        return _host_simple_ft(vals, roots)
-    L = _host_fft(vals[::2], roots[::2])
-    R = _host_fft(vals[1::2], roots[::2])
-    o = [0] * len(vals)
-    for i, (x, y) in enumerate(zip(L, R)):
-        y_times_root = y * roots[i]
-        o[i] = x + y_times_root
-        o[i + len(L)] = x - y_times_root
-    return o
-
-
-def _host_fft_1d(field, vals, modulus, root_of_unity, inv=False):
-    """starks/fft.py:316-331 on the host, ONLY for fields / orders the device code does not cover (see the module
-    docstring); element arithmetic is the field type's own."""
-    root_of_unity = field(root_of_unity)
-    rootz = [field(1), root_of_unity]
-    while rootz[-1] != field(1):
-        rootz.append(rootz[-1] * root_of_unity)
-        if len(rootz) > (1 << 16):
-            raise NotImplementedError("host transform: root order above 2^16 (use the MiMC field on the GPU)")
-    vals = [field(v) for v in vals]
-    if len(rootz) > len(vals) + 1:
-        vals = vals + [field(0)] * (len(rootz) - len(vals) - 1)
-    if inv:
-        invlen = field(len(vals)) ** (int(modulus) - 2)
-        return [x * invlen for x in _host_fft(vals, rootz[:0:-1])]
-    return _host_fft(vals, rootz[:-1])
 
 
 def fft_1d(field, vals, modulus, root_of_unity, inv=False):
     """starks/fft.py:316-331 -- the transform length is the order of root_of_unity; `vals` is zero-padded."""
     if not _on_device(modulus, root_of_unity):
-        return _host_fft_1d(field, list(vals), modulus, root_of_unity, inv)
+        return _host_dft(field, list(vals), modulus, root_of_unity, inv)
     n = _order(root_of_unity)
     vals = list(vals)
     out = ntt_bytes(_lib.to_wire(vals), n, int(root_of_unity), inverse=inv)

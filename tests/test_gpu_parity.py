@@ -961,6 +961,54 @@ def test_mimc_unit_generator_status_batch_and_trim(sa, oracle):
     pr.close()
 
 
+def test_plan_cache_is_lru_with_a_byte_budget(sa, oracle):
+    """200 distinct (n, root) shapes interleaved with a repeated hot shape under a budget that holds only a few plans: the
+    hot shape is built once and never rebuilt (least-recently-used eviction, csrc/capi.hip:evict_plans), the held bytes stay
+    inside the budget + one call's tables, and every transform still equals the oracle's."""
+    import ctypes, random
+    L = sa.lib.lib()
+    ctx = ctypes.c_void_p()
+    assert L.sh_ctx_create(0, ctypes.byref(ctx)) == 0
+    stats = (ctypes.c_uint64 * 4)()
+    try:
+        budget = 3 << 20
+        assert L.sh_ctx_set_plan_budget(ctx, budget) == 0
+        rng = random.Random(5)
+
+        def run(logn, k):
+            n = 1 << logn
+            w = pow(7, (P - 1) // n, P)
+            w = pow(w, k, P)  # another primitive root of the same order for odd k
+            vals = [rng.randrange(P) for _ in range(n)]
+            out = ctypes.create_string_buffer(32 * n)
+            assert L.sh_ntt(ctx, wire(vals), n, out, n, w.to_bytes(32, "big"), 0) == 0
+            return vals, w, out.raw
+
+        hot_vals, hot_w, hot_out = run(12, 1)
+        assert hot_out == wire(oracle.py.fft_1d(hot_vals, P, hot_w))
+        assert L.sh_ctx_stats(ctx, stats) == 0 and stats[2] == 1
+        shapes = [(logn, k) for k in range(1, 41, 2) for logn in range(5, 15)]
+        assert len(set(shapes)) == 200
+        peak = 0
+        for i, (logn, k) in enumerate(shapes):
+            if (logn, k) == (12, 1):
+                k = 41
+            vals, w, got = run(logn, k)
+            if i % 23 == 0:
+                assert got == wire(oracle.py.fft_1d(vals, P, w)), (logn, k)
+            if i % 4 == 3:  # the hot shape again: a cache hit every time
+                out = ctypes.create_string_buffer(32 << 12)
+                assert L.sh_ntt(ctx, wire(hot_vals), 1 << 12, out, 1 << 12, hot_w.to_bytes(32, "big"), 0) == 0
+                assert out.raw == hot_out
+            assert L.sh_ctx_stats(ctx, stats) == 0
+            peak = max(peak, stats[1])
+        assert stats[2] == 201, list(stats)          # 200 cold shapes + the hot one, built once
+        assert stats[3] >= 150 and stats[0] < 60, list(stats)
+        assert peak <= budget + (2 << 20), peak
+    finally:
+        L.sh_ctx_destroy(ctx)
+
+
 @pytest.mark.parametrize("args", [["--workload", "c5", "--quick"],
                                   ["--quick", "--steps", "2", "--warmup", "1", "--no-extras", "--logn", "14"]])
 def test_bench_two_ranks_share_this_gpu(sa, args):

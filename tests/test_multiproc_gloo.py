@@ -92,3 +92,20 @@ def test_bench_refuses_to_run_without_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick", "--no-cpu-baseline"], capture_output=True,
                          text=True, timeout=300, env=env)
     assert out.returncode != 0 and "{" not in out.stdout
+
+
+def test_failing_rank_ends_the_job_instead_of_hanging_it():
+    """One rank raises before the header all_gather (what an invalid witness does: mk_proof asserts, stark.py:76): the
+    launcher bench.py starts for --gpus 2 must come back non-zero promptly -- the surviving rank is ended by the launcher,
+    it does not sit in the barrier until a collective timeout."""
+    import time
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5", "--units", "11",
+                          "--dry-run", "--fail-rank", "1"], capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode != 0
+    assert "injected failure before the header all_gather" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]   # no result line from a failed job
+    assert time.time() - t0 < 200

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Bit-accurate Python model of the unsaturated 9 x 29-bit arithmetic used inside the NTT tile kernels
-(starks_amd/csrc/fp29.cuh).  Every intermediate is asserted to fit the register width the kernel uses
+(tools/fp29.cuh).  Every intermediate is asserted to fit the register width the kernel uses
 (int32 limbs, int64 columns); run it to re-validate the bounds after any change to the algorithm."""
 import random
 

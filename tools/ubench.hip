@@ -8,7 +8,7 @@
 #include <stdlib.h>
 #include <vector>
 #include "fp256.cuh"
-#include "fp29.cuh"
+#include "fp29.cuh"  // tools/fp29.cuh (the experiment is not part of the library)
 #include "blake2s.cuh"
 
 #define CK(x)                                                                      \
