@@ -19,6 +19,7 @@
 // Row pass (LAST = true): a "column" is one contiguous row of R points; rows are staged through LDS (lanes along the row
 // for the global load), and the result is scattered to natural order with 32 adjacent outputs per frequency.
 #include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <type_traits>
@@ -28,6 +29,7 @@
 #include "mfma_tw.cuh"
 #include "ntt_kernels.cuh"
 #include "ntt_tile_common.cuh"
+#include "mfma_bfly.inc"  // GENERATED (gen_bflyasm.py): the two butterfly stages as scheduled asm blocks
 
 #ifdef SHK_STAMPS
 // diagnostic build only (make STAMPS=1 -> libstarkhip_stamps.so): s_memtime at the phase boundaries of wave 0 of the
@@ -46,7 +48,37 @@ extern "C" int sh_debug_stamps(unsigned long long* out) {
 
 namespace {
 
-template <int LOG_R, bool LAST>
+// the generated stage blocks by radix
+template <int LOG_R>
+__device__ __forceinline__ void stage1_asm(shk_x8 (&x)[16], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi, uint32_t rho) {
+  if constexpr (LOG_R == 5) shk_stage1_asm_5(x, offs, lane16, mlo, mhi, rho);
+  if constexpr (LOG_R == 6) shk_stage1_asm_6(x, offs, lane16, mlo, mhi, rho);
+  if constexpr (LOG_R == 7) shk_stage1_asm_7(x, offs, lane16, mlo, mhi, rho);
+  if constexpr (LOG_R == 8) shk_stage1_asm_8(x, offs, lane16, mlo, mhi, rho);
+}
+template <int LOG_R>
+__device__ __forceinline__ void stage2_asm(shk_x8 (&x)[16], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi) {
+  if constexpr (LOG_R == 5) shk_stage2_asm_5(x, offs, lane16, mlo, mhi);
+  if constexpr (LOG_R == 6) shk_stage2_asm_6(x, offs, lane16, mlo, mhi);
+  if constexpr (LOG_R == 7) shk_stage2_asm_7(x, offs, lane16, mlo, mhi);
+  if constexpr (LOG_R == 8) shk_stage2_asm_8(x, offs, lane16, mlo, mhi);
+}
+__device__ __forceinline__ void to_x8(const fp (&x)[16], shk_x8 (&v)[16]) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[m][i] = x[m].v[i];
+}
+__device__ __forceinline__ void from_x8(const shk_x8 (&v)[16], fp (&x)[16]) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[m].v[i] = v[m][i];
+}
+
+// ASM: the butterfly stages are the generated asm blocks (mfma_bfly.inc); otherwise the C++ butterflies of mfma_tw.cuh
+// (STARKHIP_MFMA_BFLY=cxx: kept as the readable statement of the same computation and for A/B measurements)
+template <int LOG_R, bool LAST, bool ASM>
 __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu(2, 2))) ntt_ctile_kernel(NttPassArgs a) {
   static_assert(LOG_R >= 5 && LOG_R <= 8, "unsupported radix");
   constexpr int R = 1 << LOG_R;
@@ -126,7 +158,16 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
 
   // ---- stage 1: levels q = LOG_R-1 .. LOG_R-4 on the register index m (bit mu = 3 .. 0) -----------------------------
   STAMP(1);
-  {
+  shk_v16i offs;
+  const uint32_t mlo = (uint32_t)reinterpret_cast<uintptr_t>(a.mats), mhi = (uint32_t)(reinterpret_cast<uintptr_t>(a.mats) >> 32);
+  if constexpr (ASM) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offs[r] = hb ? SHK_OFFS[1][r] : SHK_OFFS[0][r];
+    shk_x8 xv[16];
+    to_x8(x, xv);
+    stage1_asm<LOG_R>(xv, offs, lane * 16u, mlo, mhi, 2u * wave);
+    from_x8(xv, x);
+  } else {
     // the fragments of butterfly j + 1 are requested before butterfly j is computed (L2 latency behind ~130 VALU
     // instructions); consecutive butterflies with the same twiddle keep their fragments
     const uint32_t rho_lo = 2u * wave, rho_hi = rho_lo + 1u;
@@ -186,6 +227,12 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
 
   STAMP(3);
   // ---- stage 2: levels q = QMAX .. 0 on the register index m' (twiddles identical for every thread) ------------------
+  if constexpr (ASM) {
+    shk_x8 xv[16];
+    to_x8(x, xv);
+    stage2_asm<LOG_R>(xv, offs, lane * 16u, mlo, mhi);
+    from_x8(xv, x);
+  } else
   static_for<QMAX + 1>([&](auto lv) {
     constexpr int q = QMAX - decltype(lv)::value;
     static_for<8>([&](auto bi) {
@@ -240,11 +287,20 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
   STAMP(5);
 }
 
-template <int LOG_R, bool LAST>
-hipError_t launch_ctile(const NttPassArgs& a, hipStream_t st) {
+bool use_asm_butterflies() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_MFMA_BFLY");
+    v = (e && !strcmp(e, "cxx")) ? 0 : 1;
+  }
+  return v == 1;
+}
+
+template <int LOG_R, bool LAST, bool ASM>
+hipError_t launch_ctile_impl(const NttPassArgs& a, hipStream_t st) {
   constexpr int R = 1 << LOG_R;
   constexpr size_t LDS = (size_t)R * 16 * 32;  // one exchange window: R rows x 16 columns
-  auto k = ntt_ctile_kernel<LOG_R, LAST>;
+  auto k = ntt_ctile_kernel<LOG_R, LAST, ASM>;
   static std::atomic<uint64_t> attr_done{0};
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -260,6 +316,11 @@ hipError_t launch_ctile(const NttPassArgs& a, hipStream_t st) {
   if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(2 * R), LDS, st, a);
   return hipGetLastError();
+}
+
+template <int LOG_R, bool LAST>
+hipError_t launch_ctile(const NttPassArgs& a, hipStream_t st) {
+  return use_asm_butterflies() ? launch_ctile_impl<LOG_R, LAST, true>(a, st) : launch_ctile_impl<LOG_R, LAST, false>(a, st);
 }
 
 template <bool LAST>
