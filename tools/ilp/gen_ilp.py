@@ -86,12 +86,62 @@ def body_mad_addmix():
         L.append("v_xor_b32_e32 v5, s20, v5")
     return L, REP * 4
 
+def body_mfma_b2b():
+    # 4 MFMAs back to back, then 60 independent VALU (mad ILP4)
+    L = []
+    for r in range(4):
+        L += ["v_mfma_i32_32x32x32_i8 v[32:47], v[24:27], v[28:31], v[32:47]", "v_mfma_i32_32x32x32_i8 v[48:63], v[24:27], v[28:31], v[48:63]",
+              "v_mfma_i32_32x32x32_i8 v[32:47], v[24:27], v[28:31], v[32:47]", "v_mfma_i32_32x32x32_i8 v[48:63], v[24:27], v[28:31], v[48:63]"]
+        for k in range(15):
+            for c in range(4):
+                L.append("v_mad_u64_u32 v[%d:%d], vcc, v%d, s20, v[%d:%d]" % (2 * c, 2 * c + 1, 20 + c, 2 * c, 2 * c + 1))
+    return L, 4 * 64
+
+def body_mfma_spread():
+    L = []
+    for r in range(4):
+        for q in range(4):
+            L.append("v_mfma_i32_32x32x32_i8 v[%d:%d], v[24:27], v[28:31], v[%d:%d]" % (32 + 16 * (q & 1), 47 + 16 * (q & 1), 32 + 16 * (q & 1), 47 + 16 * (q & 1)))
+            for k in range(15):
+                c = k % 4
+                L.append("v_mad_u64_u32 v[%d:%d], vcc, v%d, s20, v[%d:%d]" % (2 * c, 2 * c + 1, 20 + c, 2 * c, 2 * c + 1))
+    return L, 4 * 64
+
+def body_branch(every):
+    # a not-taken s_cmp / s_cbranch pair every `every` VALU instructions
+    L = []
+    n = 0
+    for r in range(REP * 4 // every):
+        for k in range(every):
+            L.append("v_xor_b32_e32 v%d, s20, v%d" % (4 + k % 4, 4 + k % 4))
+            n += 1
+        L.append("s_cmp_lg_u64 s[22:23], 0")
+        L.append("s_cbranch_scc1 SKIP%d_%%=" % r)
+        L.append("SKIP%d_%%=:" % r)
+        n += 2
+    return L, n
+
+def body_salu(every):
+    L = []
+    n = 0
+    for r in range(REP * 4 // every):
+        for k in range(every):
+            L.append("v_xor_b32_e32 v%d, s20, v%d" % (4 + k % 4, 4 + k % 4))
+            n += 1
+        L.append("s_add_u32 s28, s28, 1")
+        L.append("s_addc_u32 s29, s29, 0")
+        n += 2
+    return L, n
+
 TESTS = [("mad ILP1", body_mad(1)), ("mad ILP2", body_mad(2)), ("mad ILP3", body_mad(3)), ("mad ILP4", body_mad(4)),
          ("mad independent x4", body_mad_indep()), ("mad ILP2 + xor 1:1", body_mad_addmix()),
          ("addc chain +2 xor", body_addc(2)), ("addc chain +3 xor", body_addc(3)), ("2 addc chains +1 xor", body_addc2(1)),
          ("2 addc chains +2 xor", body_addc2(2)), ("3 addc chains", body_addc3()),
          ("xor independent x4", body_xor_indep()), ("xor dependent", body_xor_dep()), ("swap x4 indep", body_swap()),
-         ("norm (2 chains, as generated)", body_norm())]
+         ("norm (2 chains, as generated)", body_norm()),
+         ("4 MFMA back-to-back + 60 mad", body_mfma_b2b()), ("4 x (MFMA + 15 mad)", body_mfma_spread()),
+         ("xor x20 + not-taken branch", body_branch(20)), ("xor x8 + not-taken branch", body_branch(8)),
+         ("xor x8 + s_add/s_addc", body_salu(8))]
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
@@ -106,7 +156,7 @@ def main():
         out.append("    asm volatile(")
         for ln in lines:
             out.append('      "%s\\n\\t"' % ln)
-        clob = ", ".join('"v%d"' % i for i in range(80)) + ', "vcc", "s20","s22","s23","s24","s25","s26","s27"'
+        clob = ", ".join('"v%d"' % i for i in range(80)) + ', "vcc", "s20","s22","s23","s24","s25","s26","s27","s28","s29","scc"'
         out.append("      ::: %s);" % clob)
         out.append("  }")
         out.append("  t1 = __builtin_amdgcn_s_memtime();")
