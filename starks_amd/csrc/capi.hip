@@ -81,9 +81,7 @@ struct NttPlan {
   std::vector<int> radix;    // log2 radix of each pass
   std::vector<const fp2*> wR;  // per pass: powers of root^(n/R), R/2 entries, as (w, w 2^128) pairs
   std::vector<fp*> tw2;      // per column pass: [k][j2] copy of tw for the MFMA tile pass (null when it is not used)
-  std::vector<void*> mats;   // per pass: the same powers as MFMA operand images (TwMat[R/2]): C++ butterflies only, else null
-  std::vector<void*> bd;     // per pass: block-diagonal operand images of the generated asm stages (TwBD table), else null
-  std::vector<fp*> bias;     // per pass: the R bias constants that go with them
+  std::vector<void*> mats;   // per pass: the same powers as MFMA operand images (TwMat[R/2]), null for radix < 2^5
   std::vector<PowTable> tw;  // per column pass d: table of root^(P_d) (times n^-1 on pass 0 when scaled)
   PowTable base;             // unscaled table of root (sh_power_cycle, FRI fold)
   fp* scale = nullptr;       // n^-1 on the device (one-pass scaled plans)
@@ -496,8 +494,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
   int rc = build_pow_table(c, pl, root_eff, pl->log_n, nullptr, &pl->base);
   if (rc == SH_OK && pl->log_n >= 2) {
     std::map<int, const fp2*> wr_by_radix;
-    std::map<int, void*> mats_by_radix, bd_by_radix;
-    std::map<int, fp*> bias_by_radix;
+    std::map<int, void*> mats_by_radix;
     int log_P = 0;
     for (size_t d = 0; d < m && rc == SH_OK; ++d) {
       const int r = pl->radix[d];
@@ -518,19 +515,8 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         rc = upload_table(c, pl, pairs, &dev);
         wr_by_radix[r] = reinterpret_cast<const fp2*>(dev);
         mats_by_radix[r] = nullptr;
-        bd_by_radix[r] = nullptr;
-        bias_by_radix[r] = nullptr;
-        // operand images for the matrix-core butterflies (ntt_mfma.hip), only when those passes are selected: the block-diagonal
-        // images + bias constants of the generated asm stages, or the TwMat images of the C++ butterflies
-        if (rc == SH_OK && r >= 5 && r <= 8 && use_mfma_path() && shk_mfma_asm_butterflies()) {
-          std::vector<uint8_t> img(shk_bd_table_entries(r) * 4096);
-          std::vector<fp> bias((size_t)1 << r);
-          if (!shk_build_bd_table(r, t.data(), img.data(), bias.data())) rc = SH_ERR_INVALID;
-          void* d = nullptr;
-          if (rc == SH_OK) rc = upload_bytes(c, pl, img.data(), img.size(), &d);
-          bd_by_radix[r] = d;
-          if (rc == SH_OK) rc = upload_table(c, pl, bias, &bias_by_radix[r]);
-        } else if (rc == SH_OK && r >= 5 && r <= 8 && use_mfma_path()) {
+        // operand images for the matrix-core butterflies (ntt_mfma.hip), only when those passes are selected
+        if (rc == SH_OK && r >= 5 && r <= 8 && use_mfma_path()) {
           std::vector<TwMat> mm(t.size());
           for (size_t i = 0; i < t.size(); ++i)
             if (!shk_build_twmat(t[i], &mm[i])) rc = SH_ERR_INVALID;
@@ -541,8 +527,6 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
       }
       pl->wR.push_back(wr_by_radix[r]);
       pl->mats.push_back(mats_by_radix[r]);
-      pl->bd.push_back(bd_by_radix[r]);
-      pl->bias.push_back(bias_by_radix[r]);
       if (rc == SH_OK && d + 1 < m) {
         PowTable t;
         if (d == 0 && !scaled) {
@@ -642,9 +626,6 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
       a.scale = (m == 1) ? pl->scale : nullptr;
     }
     a.mats = use_mfma_path() ? pl->mats[d] : nullptr;
-    a.bd = use_mfma_path() ? pl->bd[d] : nullptr;
-    a.bias = use_mfma_path() ? pl->bias[d] : nullptr;
-    if (getenv("STARKHIP_EXPERIMENT_NOBIAS")) a.debug = 1;  // TEMPORARY timing experiment (wrong results)
 #ifdef SHK_STAMPS
     {
       const char* e = getenv("STARKHIP_STAMP_PASS");

@@ -9,12 +9,10 @@ first VALU read of its result, two between a VALU write and a v_permlane32_swap 
 a handful of serial carry chains.  With two waves per SIMD (the register tile allows no more) those slots are not hidden.
 Here every butterfly is split into streams --
 
-    P(j)  operand preparation: d = a - b and a += b side by side (both lazily reduced), d ^= 0x80..
-    M(j)  four v_mfma_i32_32x32x32_i8 with BLOCK-DIAGONAL constant operands: every lane multiplies its OWN element (no
-          cross-lane movement at all): (low | high 16 output bytes) x (low | high 16 input bytes), accumulators start from
-          the offset blocks
+    P(j)  operand preparation: TA = a ^ 0x80.., a += b (lazily reduced), b ^= 0x80.., 8 half-swaps
+    M(j)  four v_mfma_i32_32x32x32_i8 (two column groups x (W * a, -W * b)), accumulators start from the offset block
     N(j)  normalisation: 2 x 16 sums at byte spacing -> 2 x (4 limbs + carry), two interleaved mad chains
-    J(j)  join of the halves, fold of the top carry (2^256 == c), written over b
+    J(j)  5 half-swaps, join of the halves, fold of the top carry (2^256 == c), written over b
 
 -- and a list scheduler interleaves the streams of successive butterflies (oldest first, younger ones fill the slots a
 hazard would leave empty; every carry chain has its own SGPR pair), so the stage issues with (almost) no `s_nop`.
@@ -32,23 +30,20 @@ import random
 import sys
 
 P = 2**256 - 351 * 2**32 + 1
-E80 = int.from_bytes(b"\x80" * 32, "little")
 M32 = 0xffffffff
 
 # ---- physical registers -------------------------------------------------------------------------------------------------
 DATA0 = 128                      # x[m] = v[128 + 8 m .. 135 + 8 m]
-ACC1, ACC2 = 0, 16               # MFMA accumulators: low / high 16 byte positions of the lane's own product
-TA = 32                          # d = a - b, then d ^ 0x80808080 (MFMA operands: TA[0:3] = low, TA[4:7] = high 16 bytes)
-FRAG = 40                        # the four operand images of a twiddle pair: 40..43, 44..47, 48..51, 52..55
+ACC1, ACC2 = 0, 16               # MFMA accumulators (16 each)
+TA = 32                          # a ^ 0x80808080, then its swapped halves (MFMA operands a1 = TA[0:3], a2 = TA[4:7])
+FRAG = 40                        # W1 40..43, N1 44..47, W2 48..51, N2 52..55
 EZ1, EZ2 = 56, 58                # (e, 0) pairs: 64-bit addend of the first mad of a limb
 T1, T2 = 60, 62                  # mad accumulators (pairs)
 JT, JD0, JD1, JM = 64, 65, 66, 67
 SM = 68
-AM = 69                          # borrow mask of the difference chain
-# A second image buffer (loads issued a whole butterfly early) was measured: no faster (the L2 latency is already covered by
-# the normalisation and join of the previous butterfly), and its 16 registers push the kernel into spills -- one buffer.
-FRAG_B = FRAG
-NTEMP = 70                       # v0 .. v69 are clobbered
+AM = 69                          # borrow mask of the add/sub butterfly's difference chain
+FRAG_B = 70                      # second fragment buffer 70..85: the loads of butterfly j + 1 are issued a whole butterfly early
+NTEMP = 86                       # v0 .. v85 are clobbered
 # scalar scratch (clobbered)
 S_CA, S_CB, S_CJ = 64, 66, 68    # carry pairs: sum chain, (spare), join chain
 S_AD1, S_AD2 = 70, 72            # TwMat addresses of the two column groups
@@ -188,8 +183,15 @@ class Sched(object):
         self.rare = []         # out-of-line blocks: list of I
         self.nvmem = 0
         self.load_seq = {}
+        self.last_mfma = -100
 
-    def ready(self, ins):
+    MFMA_GAP = 5     # preferred number of other instructions between two MFMAs: back to back they hold the wave's issue for
+                     # 32 cycles each, with ~6 VALU instructions in between the matrix pipe runs under them (measured:
+                     # tools/ilp, "4 MFMA back-to-back + 60 mad" 10.0 vs "4 x (MFMA + 15 mad)" 9.3 cycles per instruction)
+
+    def ready(self, ins, relaxed=False):
+        if ins.kind == "mfma" and not relaxed and self.slot - self.last_mfma - 1 < self.MFMA_GAP:
+            return False
         for t in ins.need:
             if t not in self.tokens:
                 return False
@@ -238,6 +240,7 @@ class Sched(object):
         for r in ins.wr:
             self.lastw[r] = (self.slot + ins.nslots - 1, ins.kind)
         if ins.kind == "mfma":
+            self.last_mfma = self.slot
             for r in ins.rd[:8]:
                 self.lastr_mfma[r] = self.slot
         self.slot += ins.nslots
@@ -256,15 +259,20 @@ class Sched(object):
         left = sum(len(s[1]) for s in streams)
         stall = 0
         while left:
-            for k, (_, lst) in enumerate(streams):
-                h = heads[k]
-                if h < len(lst) and self.ready(lst[h]):
-                    self.emit(lst[h])
-                    heads[k] = h + 1
-                    left -= 1
-                    stall = 0
+            done = False
+            for relaxed in (False, True):   # an MFMA closer than MFMA_GAP to the previous one only instead of an s_nop
+                for k, (_, lst) in enumerate(streams):
+                    h = heads[k]
+                    if h < len(lst) and self.ready(lst[h], relaxed):
+                        self.emit(lst[h])
+                        heads[k] = h + 1
+                        left -= 1
+                        stall = 0
+                        done = True
+                        break
+                if done:
                     break
-            else:
+            if not done:
                 self.nop()
                 stall += 1
                 if stall > 64:
@@ -298,6 +306,39 @@ def rare_check(sched, pair, body, tag):
              ("rare", pair, lab, back))
 
 
+def stream_P(sched, j, m0, m1, need, give_a):
+    """TA = a ^ K, a += b (fold), b ^= K, half swaps.  a = x[m0], b = x[m1]."""
+    a = [X(m0, i) for i in range(8)]
+    b = [X(m1, i) for i in range(8)]
+    L = []
+    xa = [v_xor_k80(TA + i, a[i]) for i in range(8)]
+    xb = [v_xor_k80(b[i], b[i]) for i in range(8)]
+    s = [v_add_co(a[0], S_CA, a[0], b[0])] + [v_addc(a[i], S_CA, a[i], b[i]) for i in range(1, 8)]
+    # order: xa_i before s_i, xb_i after s_i; two fillers between consecutive carry instructions
+    L += [xa[0], xa[1], s[0], xa[2], xa[3], s[1], xa[4], xa[5], s[2], xa[6], xa[7], s[3], xb[0], xb[1], s[4], xb[2], xb[3],
+          s[5], xb[4], xb[5], s[6], xb[6], s[7], xb[7]]
+    L[0].need = tuple(need)
+    # fold of the carry out of limb 7: + c on limbs 0..1 (c = 2^256 - p = 0x15e_ffffffff)
+    L.append(v_cndmask_m1(SM, S_CA))
+    L.append(v_add_co(a[0], S_CA, a[0], SM))
+    L.append(v_and_15e(SM, SM))
+    L.append(v_addc(a[1], S_CA, a[1], SM))
+    # rare: carry out of limb 1 (limb 1 >= 2^32 - 351): propagate; a second wrap leaves a value < 2^42 -> + c again
+    body = [v_addc(a[i], S_CA, a[i], None) for i in range(2, 8)]
+    body += [v_cndmask_m1(SM, S_CA), v_add_co(a[0], S_CA, a[0], SM), v_and_15e(SM, SM), v_addc(a[1], S_CA, a[1], SM),
+             v_addc(a[2], S_CA, a[2], None)]
+    chk = rare_check(sched, S_CA, body, "S")
+    chk.give = tuple(give_a) + ("SUM%d" % j,)
+    L.append(chk)
+    # swaps: TA[i] <-> TA[4+i] and b[i] <-> b[4+i] (upper 32 lanes of the first with lower 32 lanes of the second)
+    for i in range(4):
+        L.append(v_swap(TA + i, TA + 4 + i))
+    for i in range(4):
+        L.append(v_swap(b[i], b[4 + i]))
+    L[-1].give = ("P%d" % j,)
+    return L
+
+
 def norm_chain(acc, ez, t):
     """16 non-negative sums at byte spacing (accumulator registers acc..acc+15) -> limbs in acc+0, +4, +8, +12 and the
     carry out in acc+13.  Per limb m: e = s0 + carry-in, then three v_mad_u64_u32 add s1 << 8, s2 << 16, s3 << 24; the last
@@ -323,29 +364,32 @@ def stream_N(j):
     return L
 
 
-def stream_M(j, wait, need, fr=FRAG):
-    """the four MFMAs on the lane's own operand d' = TA: acc1 = Ia x d'_lo + Ib x d'_hi + OFFS_lo (output bytes 0..15),
-    acc2 = Ic x d'_lo + Id x d'_hi + OFFS_hi (output bytes 16..31)"""
+def stream_M(j, m1, wait, need, same_frag=False, fr=FRAG):
+    """the four MFMAs: acc1 = W1 x a1 + OFFS, acc2 = W2 x a2 + OFFS, acc1 += N1 x b1, acc2 += N2 x b2
+    (same_frag: both column groups use (W1, N1) -- stage 2, where the twiddle does not depend on the lane half)"""
     L = []
     if wait:
         L.append(I("s_waitcnt vmcnt(?)", "wait", [], [], ("waitcnt?", j)))
-    L.append(v_mfma(ACC1, fr + 0, TA + 0, "%[offl]"))
-    L.append(v_mfma(ACC2, fr + 8, TA + 0, "%[offh]"))
-    L.append(v_mfma(ACC1, fr + 4, TA + 4, ACC1))
-    L.append(v_mfma(ACC2, fr + 12, TA + 4, ACC2))
+    w2, n2 = (fr + 0, fr + 4) if same_frag else (fr + 8, fr + 12)
+    L.append(v_mfma(ACC1, fr + 0, TA + 0, "%[offs]"))
+    L.append(v_mfma(ACC2, w2, TA + 4, "%[offs]"))
+    L[-1].give = ("M12_%d" % j,)
+    L.append(v_mfma(ACC1, fr + 4, X(m1, 0), ACC1))
+    L.append(v_mfma(ACC2, n2, X(m1, 4), ACC2))
     L[-1].give = ("M%d" % j,)
     L[0].need = tuple(need)
     return L
 
 
 def stream_J(sched, j, m1, give_b):
-    """acc1[0,4,8,12 | 13] = low half | carry, acc2[...] = high half | carry of the lane's own product; b = low + high << 128
-    with the top carry T folded: T 2^256 == T c = (351 T) << 32 - T."""
+    """swaps -> acc1[0,4,8,12 | 13] = own low half | carry, acc2[...] = own high half | carry; b = low + high << 128 with the
+    top carry T folded: T 2^256 == T c = (351 T) << 32 - T."""
     b = [X(m1, i) for i in range(8)]
     lo = [ACC1 + 0, ACC1 + 4, ACC1 + 8, ACC1 + 12]
     hi = [ACC2 + 0, ACC2 + 4, ACC2 + 8, ACC2 + 12]
     clo, chi = ACC1 + 13, ACC2 + 13
-    L = [v_add_co(b[4], S_CJ, hi[0], clo)]
+    L = [v_swap(clo, chi)] + [v_swap(lo[i], hi[i]) for i in range(4)]
+    L.append(v_add_co(b[4], S_CJ, hi[0], clo))
     for i in range(1, 4):
         L.append(v_addc(b[4 + i], S_CJ, hi[i], None))
     L.append(v_addc(JT, S_CJ, chi, None))             # T < 2^15 (no carry out)
@@ -367,22 +411,36 @@ def stream_J(sched, j, m1, give_b):
     return L
 
 
-def stream_F(j, base_sreg, off, need, fr=FRAG):
-    """address of the operand images (TwBD, 4 KiB) of butterfly j and their four loads"""
-    L = [I(["s_add_u32 s%d, s%d, 0x%x" % (S_AD1, base_sreg, off), "s_addc_u32 s%d, s%d, 0" % (S_AD1 + 1, base_sreg + 1)], "salu",
-           [], ["scc", "s%d" % S_AD1], ("saddr", S_AD1, base_sreg, off), need=need)]
-    for q in range(4):
-        L.append(I("global_load_dwordx4 %s, %%[lane16], %s offset:%d" % (vrng(fr + 4 * q, 4), spair(S_AD1), 1024 * q), "vmem",
-                   ["s%d" % S_AD1], [vreg(fr + 4 * q + i) for i in range(4)], ("load", fr + 4 * q, S_AD1, 1024 * q, j)))
+def stream_F(j, base_sreg, off1, off2, need, both, fr=FRAG):
+    """TwMat addresses and the fragment loads of butterfly j: AD1 = base + off1 (column group 1), AD2 = base + off2."""
+    L = []
+
+    def addr(dst, off):
+        return I(["s_add_u32 s%d, s%d, 0x%x" % (dst, base_sreg, off), "s_addc_u32 s%d, s%d, 0" % (dst + 1, base_sreg + 1)], "salu",
+                 [], ["scc", "s%d" % dst], ("saddr", dst, base_sreg, off))
+
+    def load(dreg, areg, imm):
+        return I("global_load_dwordx4 %s, %%[lane16], %s offset:%d" % (vrng(dreg, 4), spair(areg), imm), "vmem",
+                 ["s%d" % areg], [vreg(dreg + i) for i in range(4)], ("load", dreg, areg, imm, j))
+
+    L.append(addr(S_AD1, off1))
+    L[0].need = tuple(need)
+    if both:
+        L.append(addr(S_AD2, off2))
+    L.append(load(fr + 0, S_AD1, 0))
+    L.append(load(fr + 4, S_AD1, 1024))
+    if both:
+        L.append(load(fr + 8, S_AD2, 0))
+        L.append(load(fr + 12, S_AD2, 1024))
     return L
 
 
-def stream_AS(sched, j, m0, m1, need, give, mfma=False):
-    """(a, b) -> (a + b, d = a - b), two carry chains side by side, both lazily reduced.  twiddle 1 (mfma=False): d is
-    copied over b.  Otherwise d stays in TA and is offset (^ 0x80 per byte) for the MFMAs; b is written by J."""
+def stream_AS(sched, j, m0, m1, need, give):
+    """twiddle 1 (stage 2): (a, b) -> (a + b, a - b), two carry chains side by side, both lazily reduced.  The difference is
+    built in the idle fragment registers and copied over b (b feeds both chains)."""
     a = [X(m0, i) for i in range(8)]
     b = [X(m1, i) for i in range(8)]
-    d = [TA + i for i in range(8)]
+    d = [FRAG_B + i for i in range(8)]     # stage 2 needs 8 fragment registers per twiddle: its second buffer is FRAG + 8, this is free
     L = []
     sub = [I("v_sub_co_u32_e64 v%d, %s, v%d, v%d" % (d[0], spair(S_CB), a[0], b[0]), "valu", [vreg(a[0]), vreg(b[0])],
              [vreg(d[0]), spair(S_CB)], (lambda dd, aa, bb: (lambda st: st.subb(dd, S_CB, st.v(aa), st.v(bb), None)))(d[0], a[0], b[0]))]
@@ -425,83 +483,50 @@ def stream_AS(sched, j, m0, m1, need, give, mfma=False):
              I("v_subb_co_u32_e64 v%d, %s, v%d, v%d, %s" % (d[1], spair(S_CB), d[1], AM, spair(S_CB)), "valu",
                [vreg(d[1]), vreg(AM)], [vreg(d[1]), spair(S_CB)], lambda st: st.subb(d[1], S_CB, st.v(d[1]), st.v(AM), S_CB),
                carry_rd=[spair(S_CB)])]
-    chk = rare_check(sched, S_CB, body, "B")
-    chk.give = ("SUM%d" % j,)
-    L.append(chk)
-    if mfma:
-        for i in range(8):
-            L.append(v_xor_k80(d[i], d[i]))
-        L[-1].give = tuple(give) + ("P%d" % j,)
-    else:
-        for i in range(8):
-            L.append(I("v_mov_b32_e32 v%d, v%d" % (b[i], d[i]), "valu", [vreg(d[i])], [vreg(b[i])],
-                       (lambda dd, ss: (lambda st: st.setv(dd, st.v(ss))))(b[i], d[i])))
-        L[-1].give = tuple(give) + ("TAFREE%d" % j,)
+    L.append(rare_check(sched, S_CB, body, "B"))
+    for i in range(8):
+        L.append(I("v_mov_b32_e32 v%d, v%d" % (b[i], d[i]), "valu", [vreg(d[i])], [vreg(b[i])],
+                   (lambda dd, ss: (lambda st: st.setv(dd, st.v(ss))))(b[i], d[i])))
+    L[-1].give = tuple(give) + ("SUM%d" % j,)
     return L
 
 
 # ---- stages ---------------------------------------------------------------------------------------------------------------
-# Table of operand images (TwBD, 4 KiB each) of a radix-R pass, one allocation:
-#   stage 1, level mu = 3..0: entries q = (eb + rho_lo) / 2 < 2^(mu-1) G (G = R / 16): the twiddle PAIR of the two row groups of a
-#            wave, (wR^((2q) << (3-mu)), wR^((2q+1) << (3-mu))): lower lanes multiply by the first, upper lanes by the second
-#   stage 2: one entry per distinct twiddle exponent e (same twiddle for both lane halves), in bd2_exponents() order
-def bd1_level_offset(log_r):
-    G = (1 << log_r) // 16
-    sizes = [max(1, (G << mu) // 2) for mu in (3, 2, 1, 0)]
-    offs = [0]
-    for sz in sizes:
-        offs.append(offs[-1] + sz)
-    return offs   # offs[k] = first entry of level mu = 3 - k; offs[4] = first stage-2 entry
-
-
-def bd2_exponents(log_r):
-    qmax = min(log_r - 5, 3)
-    es = []
-    for q in range(qmax, -1, -1):
-        for b in range(8):
-            m0 = ((b >> q) << (q + 1)) | (b & ((1 << q) - 1))
-            e = (m0 & ((1 << q) - 1)) << (log_r - 1 - q)
-            if e and e not in es:
-                es.append(e)
-    return es
-
-
 def prologue(stage, log_r):
     L = [I("s_mov_b32 s%d, 0x80808080" % S_K80, "salu"), I("s_movk_i32 s%d, 0x100" % S_SH8, "salu"),
          I("s_mov_b32 s%d, 0x10000" % S_SH16, "salu"), I("s_mov_b32 s%d, 0x1000000" % S_SH24, "salu"),
          I("s_movk_i32 s%d, 0x15f" % S_351, "salu"), v_mov0(EZ1 + 1), v_mov0(EZ2 + 1)]
     if stage == 1:
-        # base = table + (rho_lo / 2) * 4096: the entry index of a butterfly is a compile-time part + rho_lo / 2
-        L.append(I(["s_lshl_b32 s%d, %%[rho], 11" % S_TMP, "s_add_u32 s%d, %%[mlo], s%d" % (S_BASE, S_TMP),
-                    "s_addc_u32 s%d, %%[mhi], 0" % (S_BASE + 1)], "salu", [], ["scc"], ("base", 0, 11)))
+        for k, mu in enumerate((3, 2, 1, 0)):   # base_mu = mats + (rho_lo << (3 - mu)) * sizeof(TwMat)
+            L.append(I(["s_lshl_b32 s%d, %%[rho], %d" % (S_TMP, 14 - mu),
+                        "s_add_u32 s%d, %%[mlo], s%d" % (S_BASE + 2 * k, S_TMP),
+                        "s_addc_u32 s%d, %%[mhi], 0" % (S_BASE + 2 * k + 1)], "salu", [], ["scc"], ("base", k, 14 - mu)))
     else:
         L.append(I(["s_mov_b32 s%d, %%[mlo]" % S_BASE, "s_mov_b32 s%d, %%[mhi]" % (S_BASE + 1)], "salu", [], [], ("base0",)))
     return L
 
 
 def butterflies(stage, log_r):
-    """[(m0, m1, byte offset of the butterfly's TwBD from the stage base or None for twiddle 1, (exp_lo, exp_hi shift info))]"""
+    """[(m0, m1, off1, off2 or None, base sreg)], off = byte offset of the TwMat(s); None twiddle = 1 (stage 2 only)."""
     R = 1 << log_r
     out = []
     if stage == 1:
         G = R // 16
-        lo = bd1_level_offset(log_r)
         for k, mu in enumerate((3, 2, 1, 0)):
             m0s = [((b >> mu) << (mu + 1)) | (b & ((1 << mu) - 1)) for b in range(8)]
             m0s.sort(key=lambda m: (m & ((1 << mu) - 1), m))
             for m0 in m0s:
                 eb = (m0 & ((1 << mu) - 1)) * G
-                out.append((m0, m0 | (1 << mu), (lo[k] + eb // 2) * 4096, ("s1", mu, eb)))
+                off1 = (eb << (3 - mu)) * 2048
+                out.append((m0, m0 | (1 << mu), off1, off1 + (1 << (3 - mu)) * 2048, S_BASE + 2 * k))
     else:
         qmax = min(log_r - 5, 3)
-        es = bd2_exponents(log_r)
-        first = bd1_level_offset(log_r)[4]
         for q in range(qmax, -1, -1):
             m0s = [((b >> q) << (q + 1)) | (b & ((1 << q) - 1)) for b in range(8)]
             m0s.sort(key=lambda m: (-(m & ((1 << q) - 1)), m))   # twiddle 1 (plain add / sub) last: it fills the tail
             for m0 in m0s:
                 e = (m0 & ((1 << q) - 1)) << (log_r - 1 - q)
-                out.append((m0, m0 | (1 << q), (first + es.index(e)) * 4096 if e else None, ("s2", e)))
+                out.append((m0, m0 | (1 << q), e * 2048 if e else None, None, S_BASE))
     return out
 
 
@@ -516,37 +541,39 @@ def build_stage(stage, log_r):
         sched.tokens.add("X%dv0" % m)
     streams = []
     prev_mf = None            # index of the previous MFMA butterfly
-    prev_ta = None            # token that frees TA (the previous user's last read of it)
     prev_tw = None
-    nload = 0                 # image sets loaded so far: set k lives in buffer k & 1
+    nload = 0                 # fragment sets loaded so far: set k lives in buffer k & 1
     last_user = [None, None]  # last MFMA butterfly that read each buffer
-    fr, buf = FRAG, 0
-    for j, (m0, m1, off, info) in enumerate(bf):
+    fr = FRAG
+    for j, (m0, m1, off1, off2, base) in enumerate(bf):
         need_x = ["X%dv%d" % (m0, ver[m0]), "X%dv%d" % (m1, ver[m1])]
         if j:
-            need_x.append("SUM%d" % (j - 1))  # the sum / difference chains share carry pairs and mask registers: one at a time
-        if prev_ta is not None:
-            need_x.append(prev_ta)            # ... and the difference is built in TA
+            need_x.append("SUM%d" % (j - 1))  # the sum chains share a carry pair and a mask register: one at a time
         ver[m0] += 1
         ver[m1] += 1
         give_a, give_b = ["X%dv%d" % (m0, ver[m0])], ["X%dv%d" % (m1, ver[m1])]
-        if off is None:
+        if off1 is None:
             streams.append(((j, 0), stream_AS(sched, j, m0, m1, need_x, give_a + give_b)))
-            prev_ta = "TAFREE%d" % j
             continue
-        load = off != prev_tw
-        prev_tw = off
+        tw = (base, off1, off2)
+        load = tw != prev_tw
+        prev_tw = tw
         if load:
-            buf = (nload & 1) if FRAG_B != FRAG else 0
+            buf = nload & 1
             nload += 1
-            fr = (FRAG, FRAG_B)[buf]
+            # stage 1: two sets of 16 (W1 N1 W2 N2); stage 2 (one twiddle for both column groups): two sets of 8 in FRAG
+            fr = (FRAG, FRAG_B)[buf] if stage == 1 else FRAG + 8 * buf
+        # P(j) writes TA: after the previous MFMA butterfly's first two MFMAs; J(j)/N(j) use the accumulators
+        streams.append(((j, 1), stream_P(sched, j, m0, m1, need_x + (["M12_%d" % prev_mf] if prev_mf is not None else []), give_a)))
+        if load:
             # the buffer is free once the last butterfly that read it has issued its MFMAs; priority (j - 1): the loads go out
             # a whole butterfly before their use
-            streams.append(((j - 1 if FRAG_B != FRAG else j, -1),
-                            stream_F(j, S_BASE, off, ["M%d" % last_user[buf]] if last_user[buf] is not None else [], fr)))
+            streams.append(((j - 1, -1), stream_F(j, base, off1, off2 if off2 is not None else 0,
+                                                  ["M%d" % last_user[buf]] if last_user[buf] is not None else [],
+                                                  off2 is not None, fr)))
         last_user[buf] = j
-        streams.append(((j, 1), stream_AS(sched, j, m0, m1, need_x, give_a, mfma=True)))
-        streams.append(((j, 2), stream_M(j, load, ["P%d" % j] + (["ACC%d" % prev_mf] if prev_mf is not None else []), fr=fr)))
+        streams.append(((j, 2), stream_M(j, m1, load, ["P%d" % j] + (["ACC%d" % prev_mf] if prev_mf is not None else []),
+                                         same_frag=off2 is None, fr=fr)))
         n = stream_N(j)
         n[0].need = ("M%d" % j,)
         streams.append(((j, 3), n))
@@ -554,7 +581,6 @@ def build_stage(stage, log_r):
         jj[0].need = ("N%d" % j,)
         streams.append(((j, 4), jj))
         prev_mf = j
-        prev_ta = "M%d" % j
     sched.run(streams)
     # the block ends clean: nothing the compiler's next instruction could trip over
     sched.emit(I("s_nop 1", "nop"))
@@ -589,52 +615,30 @@ def signed_digits(v):
     return d
 
 
-def twbd_bytes(w0, w1):
-    """TwBD image (4 x 1 KiB) of the twiddle pair (w0 for the lower 32 lanes, w1 for the upper 32), as shk_build_twbd lays it
-    out.  A-operand lane (i, h) feeds output row i and K slice h; row i lands in lane half (i >> 2) & 1, so only the lanes
-    with ((i >> 2) & 1) == h carry data: the lane's own 16 x 16 block.  Images: (out lo, in lo), (out lo, in hi),
-    (out hi, in lo), (out hi, in hi)."""
-    dig = []
-    for w in (w0 % P, w1 % P):
-        t, rows = w, []
+def twmat_bytes(w):
+    """TwMat image (2048 bytes: w[64][16], nw[64][16]) of the twiddle w, as shk_build_twmat lays it out."""
+    rho = lambda i: 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3)
+    out = bytearray(2048)
+    for part, val in ((0, w % P), (1, (-w) % P)):
+        t = val
+        dig = []
         for kappa in range(32):
-            rows.append(signed_digits(t))
+            dig.append(signed_digits(t))
             t = t * 256 % P
-        dig.append(rows)            # dig[h][kappa][position]
-    out = bytearray(4096)
-    for img, (po, ki) in enumerate(((0, 0), (0, 16), (16, 0), (16, 16))):
         for lane in range(64):
             i, h = lane & 31, lane >> 5
-            if ((i >> 2) & 1) != h:
-                continue
-            r = (i & 3) + 4 * (i >> 3)
             for jj in range(16):
-                out[img * 1024 + lane * 16 + jj] = dig[h][ki + jj][po + r] & 0xff
+                out[part * 1024 + lane * 16 + jj] = dig[16 * h + jj][rho(i)] & 0xff
     return bytes(out)
 
 
 def offs_block():
-    """O_j = 2^20 + delta_j for the 32 byte positions: every row sum becomes non-negative, sum O_j 2^(8j) == 0 (mod p).
-    Returns (O_0..15, O_16..31): the srcC blocks of the low / high accumulator (the same in every lane)."""
+    """[half][r] = O_(16 half + r) = 2^20 + delta: every row sum becomes non-negative, sum O_j 2^(8j) == 0 (mod p)."""
     delta = (-(2**20) * ((2**256 - 1) // 255)) % P
     db = delta.to_bytes(32, "little")
     O = [(1 << 20) + db[j] for j in range(32)]
     assert sum(o << (8 * j) for j, o in enumerate(O)) % P == 0
-    return O[:16], O[16:]
-
-
-def build_table(log_r, wR):
-    """the whole TwBD table of a radix-2^log_r pass with tile root wR (order R): bytes"""
-    R = 1 << log_r
-    G = R // 16
-    tw = [pow(wR, i, P) for i in range(R // 2)]
-    parts = []
-    for k, mu in enumerate((3, 2, 1, 0)):
-        for q in range(max(1, (G << mu) // 2)):
-            parts.append(twbd_bytes(tw[(2 * q) << (3 - mu)], tw[(2 * q + 1) << (3 - mu)]))
-    for e in bd2_exponents(log_r):
-        parts.append(twbd_bytes(tw[e], tw[e]))
-    return b"".join(parts), tw
+    return [[O[16 * h + r] for r in range(16)] for h in range(2)]
 
 
 class Sim(object):
@@ -645,8 +649,8 @@ class Sim(object):
         self.mem = mem
         self.mats_addr = mats_addr
         self.rho = rho_lo
-        ol, oh = offs_block()
-        self.offs = {"%[offl]": [[ol[r]] * 64 for r in range(16)], "%[offh]": [[oh[r]] * 64 for r in range(16)]}
+        O = offs_block()
+        self.offs = [[O[l >> 5][r] for l in range(64)] for r in range(16)]
         self.inflight = []
 
     def v(self, r):
@@ -715,7 +719,7 @@ class Sim(object):
                 i = (r & 3) + 8 * (r >> 2) + 4 * h
                 acc = sum(Amat[i][k] * Bmat[k][n] for k in range(32))
                 if isinstance(src_c, str):
-                    acc += self.offs[src_c][r][lane]
+                    acc += self.offs[r][lane]
                 else:
                     cv = self.V[src_c + r][lane]
                     acc += cv - (1 << 32) if cv >= (1 << 31) else cv
@@ -786,9 +790,9 @@ def selftest(stage, log_r, seed=1, crafted=False, verbose=False):
     R = 1 << log_r
     sched, bf = build_stage(stage, log_r)
     wR = pow(7, (P - 1) // R, P)
-    table, tw = build_table(log_r, wR)
+    tw = [pow(wR, i, P) for i in range(R // 2)]
     mats_addr = 0x10000
-    mem = bytearray(mats_addr) + table
+    mem = bytearray(mats_addr) + b"".join(twmat_bytes(t) for t in tw)
     waves = max(1, R // 32)
     wave = rng.randrange(waves)
     st = Sim(mem, mats_addr, 2 * wave)
@@ -814,21 +818,20 @@ def selftest(stage, log_r, seed=1, crafted=False, verbose=False):
     # reference: the same butterflies on integers
     ref = [list(v) for v in vals]
     G = R // 16
-    for (m0, m1, off, info) in bf:
+    for (m0, m1, off1, off2, base) in bf:
         for l in range(64):
             hb = l >> 5
-            if off is None:
+            if off1 is None:
                 w = 1
-            elif info[0] == "s1":
-                _, mu, eb = info
-                w = tw[(eb + 2 * wave + hb) << (3 - mu)]   # the reference's twiddle of row group rho = 2 wave + hb
+            elif stage == 1:
+                k = 3 - (base - S_BASE) // 2
+                idx = (off1 // 2048) + ((2 * wave + hb) << (3 - (3 - (base - S_BASE) // 2)))
+                w = tw[idx]
             else:
-                w = tw[info[1]]
+                w = tw[off1 // 2048]
             a, b = ref[m0][l], ref[m1][l]
             ref[m0][l] = (a + b) % P
-            # the MFMA multiplies the offset operand d ^ 0x80.. = d - E: the data-independent bias -w E of every such
-            # butterfly is taken out once per pass by the kernel (bias_constants(): the network's answer to a zero tile)
-            ref[m1][l] = (a - b) % P if off is None else (a - b - E80) * w % P
+            ref[m1][l] = (a - b) * w % P
     bad = 0
     for m in range(16):
         for l in range(64):
@@ -855,22 +858,14 @@ def asm_text(sched):
 
 
 def emit_inc(path):
-    ol, oh = offs_block()
+    O = offs_block()
     L = ["// GENERATED by gen_bflyasm.py -- do not edit.  The butterfly stages of ntt_mfma.hip as scheduled gfx950 asm blocks.",
          "// Registers: x[m] is pinned to v[%d + 8 m : %d + 8 m]; v0..v%d, s%d..s%d, vcc and scc are clobbered." %
          (DATA0, DATA0 + 7, NTEMP - 1, S_CA, S_LAST - 1),
          "typedef uint32_t shk_x8 __attribute__((ext_vector_type(8)));",
-         "// accumulator offsets O_j = 2^20 + delta_j of the 32 byte positions (sum O_j 2^(8j) == 0 mod p): srcC of the first MFMA",
-         "// of the low (j < 16) and of the high accumulator",
-         "#define SHK_OFFS_LO {%s}" % ", ".join(str(v) for v in ol),
-         "#define SHK_OFFS_HI {%s}" % ", ".join(str(v) for v in oh),
-         "// table layout (entries of 4 KiB): stage-1 level offsets, then the stage-2 twiddle exponents in slot order"]
-    for log_r in (5, 6, 7, 8):
-        lo = bd1_level_offset(log_r)
-        es = bd2_exponents(log_r)
-        L.append("static const int SHK_BD1_OFF_%d[5] = {%s};" % (log_r, ", ".join(str(v) for v in lo)))
-        L.append("static const int SHK_BD2_N_%d = %d;" % (log_r, len(es)))
-        L.append("static const int SHK_BD2_E_%d[%d] = {%s};" % (log_r, max(1, len(es)), ", ".join(str(v) for v in es) if es else "0"))
+         "// accumulator offsets O_(16 half + r) = 2^20 + delta (sum O_j 2^(8j) == 0 mod p): srcC of the first MFMA of a group",
+         "__device__ static const int32_t SHK_OFFS[2][16] = {{%s}, {%s}};" %
+         (", ".join(str(v) for v in O[0]), ", ".join(str(v) for v in O[1]))]
     clob = ['"v%d"' % i for i in range(NTEMP)] + ['"s%d"' % i for i in range(S_CA, S_LAST)] + ['"vcc"', '"scc"']
     L.append("#define SHK_BFLY_CLOBBERS " + ", ".join(clob))
     stats = []
@@ -880,13 +875,13 @@ def emit_inc(path):
             n = sum(i.nslots for i in sched.out if i.kind not in ("nop", "label"))
             stats.append((stage, log_r, n, sched.nops, len(bf)))
             L.append("// stage %d of a radix-2^%d tile: %d butterflies, %d instruction slots, %d s_nop" % (stage, log_r, len(bf), n, sched.nops))
-            args = "shk_x8 (&x)[16], const shk_v16i& offl, const shk_v16i& offh, uint32_t lane16, uint32_t mlo, uint32_t mhi" + (", uint32_t rho" if stage == 1 else "")
+            args = "shk_x8 (&x)[16], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi" + (", uint32_t rho" if stage == 1 else "")
             L.append("__device__ __forceinline__ void shk_stage%d_asm_%d(%s) {" % (stage, log_r, args))
             L.append("  asm volatile(")
             for t in asm_text(sched):
                 L.append('      "%s\\n\\t"' % t)
             L.append("      : " + ", ".join('"+{v[%d:%d]}"(x[%d])' % (DATA0 + 8 * m, DATA0 + 8 * m + 7, m) for m in range(16)))
-            ins = '[offl] "v"(offl), [offh] "v"(offh), [lane16] "v"(lane16), [mlo] "s"(mlo), [mhi] "s"(mhi)' + (', [rho] "s"(rho)' if stage == 1 else "")
+            ins = '[offs] "v"(offs), [lane16] "v"(lane16), [mlo] "s"(mlo), [mhi] "s"(mhi)' + (', [rho] "s"(rho)' if stage == 1 else "")
             L.append("      : " + ins)
             L.append("      : SHK_BFLY_CLOBBERS);")
             L.append("}")

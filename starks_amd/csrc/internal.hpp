@@ -26,11 +26,7 @@ struct NttPassArgs {
                       // (fft_1d's zero padding, fft.py:323-324, never materialised); 0 = the source holds n per vector
   uint32_t debug;     // diagnostic (SHK_STAMPS) builds only: 1 = this pass records its phase stamps
   const fp* tw2;      // MFMA column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k); else null
-  const void* mats;   // MFMA passes with the C++ butterflies (STARKHIP_MFMA_BFLY=cxx): TwMat[R/2], the operand images of wR[k]
-                      // (mfma_tw.cuh); else null
-  const void* bd;     // MFMA passes (ntt_mfma.hip): the TwBD table of the radix (block-diagonal operand images, layout in
-                      // mfma_bfly.inc / gen_bflyasm.py), else null
-  const fp* bias;     // ... and the R per-position constants that take the operand-offset bias of the MFMA butterflies out
+  const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null
   uint32_t xcd_per;   // 0: tile = blockIdx.x.  Else workgroups are dealt to the 8 XCDs round-robin and tile = (blockIdx.x & 7) *
                       // xcd_per + (blockIdx.x >> 3): adjacent tiles run on the SAME XCD (they share 128-byte lines when T < 4)
   uint32_t sharers;   // column passes with xcd_per: the number of (vector, prefix block) pairs = total >> log_S, all of which
@@ -46,12 +42,6 @@ hipError_t shk_launch_ntt_tiny(const fp* src, fp* dst, uint32_t n, uint32_t batc
 // cores; supports radix 2^5 .. 2^8, column passes with S >= 32 and every row pass
 bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a);
 hipError_t shk_launch_ntt_pass_mfma(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
-// the generated asm stages (default) or the C++ butterflies (STARKHIP_MFMA_BFLY=cxx) run the MFMA passes; the asm stages
-// read the TwBD table (shk_bd_table_entries(log_R) entries of 4096 bytes) and the R bias constants built by shk_build_bd_table
-// from the tile twiddles tw[k] = wR^k, k < R/2
-bool shk_mfma_asm_butterflies();
-size_t shk_bd_table_entries(int log_R);
-bool shk_build_bd_table(int log_R, const fp* tw, void* table_out, fp* bias_out);
 constexpr int SHK_TILE_LOG = 10;  // default tile: 1024 elements (32 KiB of LDS, 256 threads) per workgroup -> 5 workgroups per CU
 
 // ---- kernels.hip: conversions, powers, Merkle, FRI fold, sampling, branch gather ------------------

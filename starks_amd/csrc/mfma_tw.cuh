@@ -235,40 +235,3 @@ inline bool shk_build_twmat(const fp& w, TwMat* out) {
   }
   return true;
 }
-
-// ---- block-diagonal operand images (the generated asm stages: gen_bflyasm.py, mfma_bfly.inc) --------------------------------
-// One 4 KiB entry per twiddle PAIR (w0 for the elements of lanes 0..31, w1 for lanes 32..63): four MFMA A operands whose
-// only non-zero part is the 16 x 16 block that multiplies a lane's OWN bytes -- A-operand lane (i, h) feeds output row i
-// and K slice h, and row i lands in lane half (i >> 2) & 1, so exactly the lanes with ((i >> 2) & 1) == h carry data.
-// With them every lane multiplies its own element: no v_permlane32_swap anywhere in a butterfly.
-//   img[0]: output bytes 0..15  x input bytes 0..15      img[1]: output bytes 0..15  x input bytes 16..31
-//   img[2]: output bytes 16..31 x input bytes 0..15      img[3]: output bytes 16..31 x input bytes 16..31
-struct TwBD {
-  uint32_t img[4][64][4];
-};
-static_assert(sizeof(TwBD) == 4096, "TwBD layout");
-
-inline bool shk_build_twbd(const fp& w0, const fp& w1, TwBD* out) {
-  using namespace shk_twmat_detail;
-  int8_t dig[2][32][32];  // [half][kappa][position]
-  const fp k256 = fp_from_u32(256u);
-  for (int h = 0; h < 2; ++h) {
-    fp t = fp_canon(h ? w1 : w0);
-    for (int kappa = 0; kappa < 32; ++kappa) {
-      if (!signed_digits(t, dig[h][kappa])) return false;
-      t = fp_canon(fp_mul(t, k256));
-    }
-  }
-  memset(out, 0, sizeof(TwBD));
-  static const int po[4] = {0, 0, 16, 16}, ki[4] = {0, 16, 0, 16};
-  for (int im = 0; im < 4; ++im)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int i = lane & 31, h = lane >> 5;
-      if (((i >> 2) & 1) != h) continue;
-      const int r = (i & 3) + 4 * (i >> 3);
-      uint8_t b[16];
-      for (int j = 0; j < 16; ++j) b[j] = (uint8_t)dig[h][ki[im] + j][po[im] + r];
-      memcpy(out->img[im][lane], b, 16);
-    }
-  return true;
-}

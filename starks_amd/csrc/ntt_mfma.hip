@@ -24,7 +24,6 @@
 #include <atomic>
 #include <type_traits>
 #include <utility>
-#include <vector>
 
 #include "internal.hpp"
 #include "mfma_tw.cuh"
@@ -51,20 +50,18 @@ namespace {
 
 // the generated stage blocks by radix
 template <int LOG_R>
-__device__ __forceinline__ void stage1_asm(shk_x8 (&x)[16], const shk_v16i& offl, const shk_v16i& offh, uint32_t lane16, uint32_t mlo,
-                                           uint32_t mhi, uint32_t rho) {
-  if constexpr (LOG_R == 5) shk_stage1_asm_5(x, offl, offh, lane16, mlo, mhi, rho);
-  if constexpr (LOG_R == 6) shk_stage1_asm_6(x, offl, offh, lane16, mlo, mhi, rho);
-  if constexpr (LOG_R == 7) shk_stage1_asm_7(x, offl, offh, lane16, mlo, mhi, rho);
-  if constexpr (LOG_R == 8) shk_stage1_asm_8(x, offl, offh, lane16, mlo, mhi, rho);
+__device__ __forceinline__ void stage1_asm(shk_x8 (&x)[16], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi, uint32_t rho) {
+  if constexpr (LOG_R == 5) shk_stage1_asm_5(x, offs, lane16, mlo, mhi, rho);
+  if constexpr (LOG_R == 6) shk_stage1_asm_6(x, offs, lane16, mlo, mhi, rho);
+  if constexpr (LOG_R == 7) shk_stage1_asm_7(x, offs, lane16, mlo, mhi, rho);
+  if constexpr (LOG_R == 8) shk_stage1_asm_8(x, offs, lane16, mlo, mhi, rho);
 }
 template <int LOG_R>
-__device__ __forceinline__ void stage2_asm(shk_x8 (&x)[16], const shk_v16i& offl, const shk_v16i& offh, uint32_t lane16, uint32_t mlo,
-                                           uint32_t mhi) {
-  if constexpr (LOG_R == 5) shk_stage2_asm_5(x, offl, offh, lane16, mlo, mhi);
-  if constexpr (LOG_R == 6) shk_stage2_asm_6(x, offl, offh, lane16, mlo, mhi);
-  if constexpr (LOG_R == 7) shk_stage2_asm_7(x, offl, offh, lane16, mlo, mhi);
-  if constexpr (LOG_R == 8) shk_stage2_asm_8(x, offl, offh, lane16, mlo, mhi);
+__device__ __forceinline__ void stage2_asm(shk_x8 (&x)[16], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi) {
+  if constexpr (LOG_R == 5) shk_stage2_asm_5(x, offs, lane16, mlo, mhi);
+  if constexpr (LOG_R == 6) shk_stage2_asm_6(x, offs, lane16, mlo, mhi);
+  if constexpr (LOG_R == 7) shk_stage2_asm_7(x, offs, lane16, mlo, mhi);
+  if constexpr (LOG_R == 8) shk_stage2_asm_8(x, offs, lane16, mlo, mhi);
 }
 __device__ __forceinline__ void to_x8(const fp (&x)[16], shk_x8 (&v)[16]) {
 #pragma unroll
@@ -161,12 +158,14 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
 
   // ---- stage 1: levels q = LOG_R-1 .. LOG_R-4 on the register index m (bit mu = 3 .. 0) -----------------------------
   STAMP(1);
-  const shk_v16i offl = SHK_OFFS_LO, offh = SHK_OFFS_HI;
-  const uint32_t mlo = (uint32_t)reinterpret_cast<uintptr_t>(a.bd), mhi = (uint32_t)(reinterpret_cast<uintptr_t>(a.bd) >> 32);
+  shk_v16i offs;
+  const uint32_t mlo = (uint32_t)reinterpret_cast<uintptr_t>(a.mats), mhi = (uint32_t)(reinterpret_cast<uintptr_t>(a.mats) >> 32);
   if constexpr (ASM) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) offs[r] = hb ? SHK_OFFS[1][r] : SHK_OFFS[0][r];
     shk_x8 xv[16];
     to_x8(x, xv);
-    stage1_asm<LOG_R>(xv, offl, offh, lane * 16u, mlo, mhi, 2u * wave);
+    stage1_asm<LOG_R>(xv, offs, lane * 16u, mlo, mhi, 2u * wave);
     from_x8(xv, x);
   } else {
     // the fragments of butterfly j + 1 are requested before butterfly j is computed (L2 latency behind ~130 VALU
@@ -231,14 +230,8 @@ __global__ void __launch_bounds__(2 << LOG_R) __attribute__((amdgpu_waves_per_eu
   if constexpr (ASM) {
     shk_x8 xv[16];
     to_x8(x, xv);
-    stage2_asm<LOG_R>(xv, offl, offh, lane * 16u, mlo, mhi);
+    stage2_asm<LOG_R>(xv, offs, lane * 16u, mlo, mhi);
     from_x8(xv, x);
-    // the MFMA butterflies multiply the offset operand d - E (E = 0x80 in every byte): the sum of those data-independent
-    // terms at position i is -bias[i] (shk_build_bd_table), taken out here, once per pass
-    if (!a.debug) {
-#pragma unroll
-      for (int m = 0; m < 16; ++m) x[m] = fp_add(x[m], fp_load(a.bias + 16u * rho + (uint32_t)m));
-    }
   } else
   static_for<QMAX + 1>([&](auto lv) {
     constexpr int q = QMAX - decltype(lv)::value;
@@ -343,68 +336,8 @@ hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool shk_mfma_asm_butterflies() { return use_asm_butterflies(); }
-
-size_t shk_bd_table_entries(int log_R) {
-  switch (log_R) {
-    case 5: return (size_t)SHK_BD1_OFF_5[4] + SHK_BD2_N_5;
-    case 6: return (size_t)SHK_BD1_OFF_6[4] + SHK_BD2_N_6;
-    case 7: return (size_t)SHK_BD1_OFF_7[4] + SHK_BD2_N_7;
-    case 8: return (size_t)SHK_BD1_OFF_8[4] + SHK_BD2_N_8;
-    default: return 0;
-  }
-}
-
-// Host: the TwBD table of a radix-2^log_R tile pass whose in-tile twiddles are tw[k] = wR^k (k < R/2), in the layout the
-// generated stages address (gen_bflyasm.py: bd1_level_offset / bd2_exponents), and the R bias constants: bias[i] = minus what
-// the same butterfly network -- every MFMA butterfly computing (a - b - E) w instead of (a - b) w -- makes of an all-zero tile
-// at position i (the network is linear, so that is exactly the error of every tile).
-bool shk_build_bd_table(int log_R, const fp* tw, void* table_out, fp* bias_out) {
-  const int *off1 = nullptr, *e2 = nullptr;
-  int n2 = 0;
-  switch (log_R) {
-    case 5: off1 = SHK_BD1_OFF_5; e2 = SHK_BD2_E_5; n2 = SHK_BD2_N_5; break;
-    case 6: off1 = SHK_BD1_OFF_6; e2 = SHK_BD2_E_6; n2 = SHK_BD2_N_6; break;
-    case 7: off1 = SHK_BD1_OFF_7; e2 = SHK_BD2_E_7; n2 = SHK_BD2_N_7; break;
-    case 8: off1 = SHK_BD1_OFF_8; e2 = SHK_BD2_E_8; n2 = SHK_BD2_N_8; break;
-    default: return false;
-  }
-  const int R = 1 << log_R, G = R / 16;
-  TwBD* t = static_cast<TwBD*>(table_out);
-  for (int k = 0; k < 4; ++k) {
-    const int mu = 3 - k, cnt = off1[k + 1] - off1[k];
-    for (int q = 0; q < cnt; ++q)
-      if (!shk_build_twbd(tw[(2 * q) << (3 - mu)], tw[(2 * q + 1) << (3 - mu)], &t[off1[k] + q])) return false;
-  }
-  for (int s = 0; s < n2; ++s)
-    if (!shk_build_twbd(tw[e2[s]], tw[e2[s]], &t[off1[4] + s])) return false;
-  // the network on a zero tile.  Stage 1 (levels LOG_R-1 .. LOG_R-4) runs every butterfly on the matrix cores, stage 2
-  // (levels min(LOG_R-5, 3) .. 0) only those with a twiddle other than 1.
-  (void)G;
-  fp E;
-  for (int i = 0; i < 8; ++i) E.v[i] = 0x80808080u;
-  std::vector<fp> z((size_t)R, fp_zero());
-  const int qmax2 = log_R - 5 < 3 ? log_R - 5 : 3;
-  for (int q = log_R - 1; q >= 0; --q) {
-    const bool stage1 = q >= log_R - 4;
-    if (!stage1 && q > qmax2) return false;  // cannot happen: 4 + qmax2 + 1 == log_R for log_R <= 8
-    for (int i = 0; i < R; ++i) {
-      if (i & (1 << q)) continue;
-      const int e = (i & ((1 << q) - 1)) << (log_R - 1 - q);
-      const fp a = z[i], b = z[i + (1 << q)];
-      z[i] = fp_add(a, b);
-      fp d = fp_sub(a, b);
-      if (stage1 || e != 0) d = fp_mul(fp_sub(d, E), tw[e]);
-      z[i + (1 << q)] = d;
-    }
-  }
-  for (int i = 0; i < R; ++i) bias_out[i] = fp_canon(fp_neg(z[i]));
-  return true;
-}
-
 bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a) {
-  if (log_R < 5 || log_R > 8) return false;
-  if (use_asm_butterflies() ? (!a.bd || !a.bias) : !a.mats) return false;
+  if (log_R < 5 || log_R > 8 || !a.mats) return false;
   if (!last && (a.log_S < 5 || !a.tw2)) return false;  // a tile's 32 columns must be adjacent
   return true;
 }
