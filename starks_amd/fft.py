@@ -130,7 +130,12 @@ def mul_polys(a, b, root_of_unity):
             break
     if field is None:
         field = IntegersModP(MIMC_P)
-    _check_field(field.p)
+    if not _on_device(field.p, root_of_unity):
+        # another field or an order the device code does not cover: three direct transforms on the host (never the hot path)
+        fa = _host_dft(field, list(a), field.p, root_of_unity)
+        fb = _host_dft(field, list(b), field.p, root_of_unity)
+        unscale = field(len(fa))  # _host_dft's inverse divides by n, mul_polys (fft.py:345) does not
+        return [x * unscale for x in _host_dft(field, [u * v for u, v in zip(fa, fb)], field.p, root_of_unity, inv=True)]
     n = _order(root_of_unity)
     a, b = list(a), list(b)
     if len(a) > n or len(b) > n:

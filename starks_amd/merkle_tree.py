@@ -22,18 +22,31 @@ def get_index_in_permuted(x, L):
     return x // q + 4 * (x % q)
 
 
+def _leaf_list(L):
+    """merkle_tree.py:47-53: ints as 32 big-endian bytes, byte strings as they are, field elements through to_bytes()"""
+    return [x if isinstance(x, bytes) else x.to_bytes(32, "big") if isinstance(x, int) else x.to_bytes() for x in L]
+
+
 def _leaf_bytes(L):
-    out = []
-    for x in L:
-        if isinstance(x, bytes):
-            if len(x) != 32:
-                raise NotImplementedError("starks_amd.merkelize hashes 32-byte leaves (field elements) only")
-            out.append(x)
-        elif isinstance(x, int):
-            out.append(x.to_bytes(32, "big"))
-        else:
-            out.append(x.to_bytes())
+    out = _leaf_list(L)
+    if any(len(x) != 32 for x in out):
+        raise NotImplementedError("the device tree hashes 32-byte leaves (field elements) only")
     return b"".join(out)
+
+
+def _host_merkelize(leaves):
+    """Trees the device code does not cover -- leaves that are not 32-byte values, or a leaf count that is not a power of two
+    >= 4 (the reference hashes whatever to_bytes gives and any length, merkle_tree.py:36-56) -- on the host, never the hot path:
+    the same heap layout, filled a generation at a time (the parents lo..hi-1 of the nodes 2 lo..2 hi-1)."""
+    leaves = permute4(leaves)
+    n = len(leaves)
+    nodes = [b""] * n + leaves
+    hi = n
+    while hi > 1:
+        lo = (hi + 1) // 2
+        nodes[lo:hi] = [blake(a + b) for a, b in zip(nodes[2 * lo:2 * hi:2], nodes[2 * lo + 1:2 * hi:2])]
+        hi = lo
+    return nodes
 
 
 def merkelize_bytes(leaves):
@@ -47,8 +60,13 @@ def merkelize_bytes(leaves):
 
 
 def merkelize(L):
-    """merkle_tree.py:36-56.  Leaves may be ints, 32-byte strings or field elements (:47-53)."""
-    raw = merkelize_bytes(_leaf_bytes(list(L)))
+    """merkle_tree.py:36-56.  Leaves may be ints, byte strings or field elements (:47-53).  Power-of-two counts (>= 4) of
+    32-byte leaves -- every tree of the proving path -- are hashed on the GPU; anything else on the host."""
+    leaves = _leaf_list(list(L))
+    n = len(leaves)
+    if n < 4 or n & (n - 1) or any(len(x) != 32 for x in leaves):
+        return _host_merkelize(leaves)
+    raw = merkelize_bytes(b"".join(leaves))
     nodes = [raw[i:i + 32] for i in range(0, len(raw), 32)]
     nodes[0] = b""  # the reference leaves b'' in slot 0
     return nodes

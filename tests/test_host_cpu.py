@@ -312,3 +312,34 @@ def test_generated_mfma_stages_simulate_correctly():
         g.emit_inc(out)
         assert open(out).read() == open(os.path.join(ROOT, "starks_amd", "csrc", "mfma_bfly.inc")).read(), \
             "mfma_bfly.inc is stale: run python3 starks_amd/csrc/gen_bflyasm.py"
+
+
+def test_host_generality_outside_the_hot_path():
+    """What the device code cannot represent stays available through the reference's call sites, on the host: merkelize of
+    leaves that are not 32-byte values or not a power-of-two count (merkle_tree.py:36-56 hashes whatever to_bytes gives),
+    mul_polys over another field (fft.py:334-345).  Checked against hashlib / schoolbook arithmetic -- no GPU, no oracle."""
+    import random
+    from hashlib import blake2s
+    from starks_amd import merkle_tree as mt
+    from starks_amd import fft
+    from starks_amd.modp import IntegersModP
+    rng = random.Random(9)
+    for n in (1, 3, 4, 6, 7, 12, 16):
+        L = [rng.randbytes(rng.choice([5, 32, 40])) for _ in range(n)]
+        nodes = mt.merkelize(L)
+        q = n // 4
+        perm = [L[i + j * q] for i in range(q) for j in range(4)]
+        m = len(perm)
+        assert len(nodes) == 2 * m and nodes[m:] == perm
+        for i in range(1, m):
+            assert nodes[i] == blake2s(nodes[2 * i] + nodes[2 * i + 1]).digest()
+    F = IntegersModP(31)
+    for root, order in ((2, 5), (6, 6), (15, 10), (3, 30)):
+        a = [rng.randrange(31) for _ in range(order // 2)]
+        b = [rng.randrange(31) for _ in range(order - order // 2)]
+        got = [int(x) for x in fft.mul_polys([F(x) for x in a], [F(x) for x in b], F(root))]
+        prod = [0] * order
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                prod[(i + j) % order] = (prod[(i + j) % order] + x * y) % 31
+        assert got == [(order * v) % 31 for v in prod]   # n * (a * b): the reference omits the 1/n (fft.py:345)

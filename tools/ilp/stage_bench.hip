@@ -12,13 +12,14 @@ template <int STAGE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k(const shk_x8* in, shk_x8* out, const void* table, unsigned long long* cyc, int iters) {
   shk_x8 x[16];
   for (int m = 0; m < 16; ++m) x[m] = in[(blockIdx.x * 256 + threadIdx.x) * 16 + m];
-  const shk_v16i offl = SHK_OFFS_LO, offh = SHK_OFFS_HI;
+  shk_v16i offs;
+  for (int r = 0; r < 16; ++r) offs[r] = (threadIdx.x & 32) ? SHK_OFFS[1][r] : SHK_OFFS[0][r];
   const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t mlo = (uint32_t)reinterpret_cast<uintptr_t>(table), mhi = (uint32_t)(reinterpret_cast<uintptr_t>(table) >> 32);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
-    if (STAGE == 1) shk_stage1_asm_7(x, offl, offh, lane * 16u, mlo, mhi, 2u * wave);
-    else shk_stage2_asm_7(x, offl, offh, lane * 16u, mlo, mhi);
+    if (STAGE == 1) shk_stage1_asm_7(x, offs, lane * 16u, mlo, mhi, 2u * wave);
+    else shk_stage2_asm_7(x, offs, lane * 16u, mlo, mhi);
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   for (int m = 0; m < 16; ++m) out[(blockIdx.x * 256 + threadIdx.x) * 16 + m] = x[m];
