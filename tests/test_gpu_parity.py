@@ -145,8 +145,8 @@ def test_reference_call_sites_fft(sa):
     # mod-31 / order-6 inputs (test_fft.py:98-113) are outside the accelerated field: host recursion, reference KAT
     F31 = sa.pkg.IntegersModP(31)
     assert [int(v) for v in sa.fft.fft_1d(F31, [0, 1, 2, 3], 31, F31(26))] == g["mod31_n6"]["fwd"]
-    with pytest.raises(NotImplementedError):  # mul_polys stays MiMC-only
-        sa.fft.mul_polys([F31(1)], [F31(1)], F31(26))
+    # mul_polys over another field: host transforms (round 3); n * (a * b), the reference omits the 1/n (fft.py:345)
+    assert [int(v) for v in sa.fft.mul_polys([F31(1), F31(2)], [F31(3)], F31(26))] == [(6 * 3) % 31, (6 * 6) % 31, 0, 0, 0, 0]
 
 
 def test_power_cycle(sa):
