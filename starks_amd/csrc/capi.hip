@@ -95,6 +95,7 @@ struct NttPlan {
 struct sh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t io_in = nullptr, io_out = nullptr;  // copy streams of the pipelined host-buffer transforms (created on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   std::map<std::string, NttPlan*> plans;
@@ -1086,6 +1087,8 @@ void sh_ctx_destroy(sh_ctx* c) {
   }
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->io_in) (void)hipStreamDestroy(c->io_in);
+  if (c->io_out) (void)hipStreamDestroy(c->io_out);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1291,6 +1294,64 @@ static int download_wire(sh_ctx* c, const fp* d, uint8_t* out, uint64_t count) {
   return d2h(c, out, w, (size_t)count * 32);
 }
 
+// Several vectors from page-locked host buffers: the vectors go through in up to 8 chunks, H2D on one copy stream, wire -> limb,
+// transform, limb -> wire on the ctx stream, D2H on a second copy stream, chained by events -- the upload of chunk k + 1 and the
+// download of chunk k - 1 run under the transform of chunk k (PCIe is full duplex), instead of upload, transform, download in a row.
+static int ntt_batch_pipelined(sh_ctx* c, NttPlan* pl, const uint8_t* in, uint8_t* out, uint64_t n, uint32_t batch) {
+  const uint32_t nch = batch < 8 ? batch : 8;
+  const uint32_t per = (batch + nch - 1) / nch;
+  void *w_in = nullptr, *x = nullptr, *w_out = nullptr, *ntt_ws = nullptr;
+  SH_TRY(ws_get(c, sh_ctx::WS_WIRE, (size_t)batch * n * 32, &w_in));
+  SH_TRY(ws_get(c, sh_ctx::WS_X, (size_t)batch * n * sizeof(fp), &x));
+  SH_TRY(ws_get(c, sh_ctx::WS_Y, (size_t)batch * n * 32, &w_out));
+  SH_TRY(ws_get(c, sh_ctx::WS_NTT, (size_t)per * n * sizeof(fp), &ntt_ws));  // sized once: run_ntt must not reallocate mid-pipeline
+  if (!c->io_in) HIP_TRY(c, hipStreamCreateWithFlags(&c->io_in, hipStreamNonBlocking));
+  if (!c->io_out) HIP_TRY(c, hipStreamCreateWithFlags(&c->io_out, hipStreamNonBlocking));
+  struct Events {
+    hipEvent_t e[17] = {};
+    ~Events() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+  } ev;
+  for (uint32_t k = 0; k < 2 * nch + 1; ++k) HIP_TRY(c, hipEventCreateWithFlags(&ev.e[k], hipEventDisableTiming));
+  // earlier work on the ctx stream may still use the workspaces: the uploads start behind it
+  HIP_TRY(c, hipEventRecord(ev.e[2 * nch], c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->io_in, ev.e[2 * nch], 0));
+  int rc = SH_OK;
+  for (uint32_t k = 0; k < nch && rc == SH_OK; ++k) {
+    const uint64_t v0 = (uint64_t)k * per, v1 = v0 + per < batch ? v0 + per : batch;
+    if (v0 >= v1) break;
+    const size_t off = (size_t)v0 * n * 32, len = (size_t)(v1 - v0) * n * 32;
+    hipError_t e = hipMemcpyAsync(static_cast<uint8_t*>(w_in) + off, in + off, len, hipMemcpyHostToDevice, c->io_in);
+    if (e == hipSuccess) e = hipEventRecord(ev.e[k], c->io_in);
+    if (e != hipSuccess) rc = SH_ERR_HIP;
+  }
+  for (uint32_t k = 0; k < nch && rc == SH_OK; ++k) {
+    const uint64_t v0 = (uint64_t)k * per, v1 = v0 + per < batch ? v0 + per : batch;
+    if (v0 >= v1) break;
+    const size_t off = (size_t)v0 * n * 32, len = (size_t)(v1 - v0) * n * 32;
+    fp* xk = reinterpret_cast<fp*>(x) + v0 * n;
+    hipError_t e = hipStreamWaitEvent(c->stream, ev.e[k], 0);
+    if (e == hipSuccess) e = shk_wire_to_limb(static_cast<uint8_t*>(w_in) + off, xk, (v1 - v0) * n, c->stream);
+    if (e != hipSuccess) { rc = SH_ERR_HIP; break; }
+    rc = run_ntt(c, pl, xk, xk, (uint32_t)(v1 - v0));
+    if (rc != SH_OK) break;
+    e = shk_limb_to_wire(xk, static_cast<uint8_t*>(w_out) + off, (v1 - v0) * n, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev.e[nch + k], c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->io_out, ev.e[nch + k], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(out + off, static_cast<uint8_t*>(w_out) + off, len, hipMemcpyDeviceToHost, c->io_out);
+    if (e != hipSuccess) rc = SH_ERR_HIP;
+  }
+  // whatever happened, nothing of this call may still be in flight when the caller's buffers and the events go away
+  (void)hipStreamSynchronize(c->io_in);
+  (void)hipStreamSynchronize(c->stream);
+  const hipError_t es = hipStreamSynchronize(c->io_out);
+  if (rc == SH_OK && es != hipSuccess) rc = SH_ERR_HIP;
+  if (rc == SH_ERR_HIP && c->err.empty()) c->err = "pipelined transform: HIP error";
+  return rc;
+}
+
 int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint64_t n, uint32_t batch,
                  const uint8_t root[32], int inverse) {
   if (!c || !out || !root || (n_in && !in) || batch == 0) return SH_ERR_INVALID;
@@ -1298,6 +1359,9 @@ int sh_ntt_batch(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint8_t* out, uint
   SH_TRY(enter(c));
   NttPlan* pl = nullptr;
   SH_TRY(plan_for(c, root, n, inverse != 0, &pl, batch));
+  if (batch >= 2 && n_in == n && n >= (1u << 12) && (size_t)batch * n * 32 >= ((size_t)4 << 20) && host_is_pinned(in) &&
+      host_is_pinned(out))
+    return ntt_batch_pipelined(c, pl, in, out, n, batch);
   fp* x = nullptr;
   uint64_t n_short = 0;
   SH_TRY(upload_short(c, in, n_in, n, batch, sh_ctx::WS_X, &x, &n_short));

@@ -961,6 +961,39 @@ def test_mimc_unit_generator_status_batch_and_trim(sa, oracle):
     pr.close()
 
 
+def test_pinned_batch_transform_is_pipelined_and_identical(sa, oracle):
+    """sh_ntt_batch from page-locked buffers moves its vectors through in chunks (upload / transform / download overlapped on
+    three streams, csrc/capi.hip:ntt_batch_pipelined): every vector must equal the one-at-a-time result and the oracle's."""
+    import random
+    rng = random.Random(3)
+    n, B = 1 << 15, 5   # 5 MiB: above the pipelining threshold, a chunk count that does not divide evenly into 8
+    w = root_of(n)
+    vecs = [[rng.randrange(P) for _ in range(n)] for _ in range(B)]
+    src, dst = sa.lib.PinnedBuffer(32 * n * B), sa.lib.PinnedBuffer(32 * n * B)
+    try:
+        src.view[:] = b"".join(wire(v) for v in vecs)
+        for inverse in (False, True):
+            sa.fft.ntt_bytes(src, n, w, inverse=inverse, batch=B, out=dst)
+            got = bytes(dst.view)
+            for b in range(B):
+                one = sa.fft.ntt_bytes(wire(vecs[b]), n, w, inverse=inverse)
+                assert got[32 * n * b:32 * n * (b + 1)] == one, (inverse, b)
+            assert got[:32 * n] == wire(oracle.py.fft_1d(vecs[0], P, w, inv=inverse))
+        # 11 vectors: more vectors than chunks
+        B2 = 11
+        src2, dst2 = sa.lib.PinnedBuffer(32 * n * B2), sa.lib.PinnedBuffer(32 * n * B2)
+        try:
+            src2.view[:] = b"".join(wire(vecs[b % B]) for b in range(B2))
+            sa.fft.ntt_bytes(src2, n, w, batch=B2, out=dst2)
+            got2 = bytes(dst2.view)
+            one = [sa.fft.ntt_bytes(wire(v), n, w) for v in vecs]
+            assert all(got2[32 * n * b:32 * n * (b + 1)] == one[b % B] for b in range(B2))
+        finally:
+            src2.close(); dst2.close()
+    finally:
+        src.close(); dst.close()
+
+
 def test_plan_cache_is_lru_with_a_byte_budget(sa, oracle):
     """200 distinct (n, root) shapes interleaved with a repeated hot shape under a budget that holds only a few plans: the
     hot shape is built once and never rebuilt (least-recently-used eviction, csrc/capi.hip:evict_plans), the held bytes stay
