@@ -638,6 +638,10 @@ def main():
                      "kernel": "%s (%d launches per 2^%d transform; all passes of both directions averaged)" %
                                ("ntt_ctile_kernel" if path == "mfma" else "ntt_pass_kernel", passes, args.logn),
                      "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
+                     # the same launches by the bytes they really move (PMC traffic per launch / live launch duration): how far
+                     # the pass is from the memory roof, as opposed to `frac`, which counts every element once per transform
+                     "hbm_traffic_GBps": (traffic / (ev_ms.value * 1e-3 / (2 * passes * args.steps)) / 1e9) if traffic else None,
+                     "hbm_traffic_frac": (traffic / (ev_ms.value * 1e-3 / (2 * passes * args.steps)) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "note": "integer-VALU bound, not HBM bound; see DESIGN.md section 5"},
     }
     if rank == 0 and world == 1 and not args.no_single:
