@@ -54,6 +54,12 @@ def ntt_bytes(data, n, root_of_unity, inverse=False, batch=1, out=None):
     return out if out is not None else dst.raw
 
 
+def _elements(field, ints):
+    """device output (canonical residues) -> elements of the caller's field type"""
+    wrap = getattr(field, "wrap_canonical", None)
+    return wrap(ints) if wrap is not None else [field(x) for x in ints]
+
+
 def _on_device(modulus, root_of_unity):
     return int(modulus) == MIMC_P and _lib.order_of_root(root_of_unity) is not None
 
@@ -97,7 +103,7 @@ def fft_1d(field, vals, modulus, root_of_unity, inv=False):
     n = _order(root_of_unity)
     vals = list(vals)
     out = ntt_bytes(_lib.to_wire(vals), n, int(root_of_unity), inverse=inv)
-    return [field(x) for x in _lib.from_wire(out)]
+    return _elements(field, _lib.from_wire(out))
 
 
 class FFT(object):
@@ -144,7 +150,7 @@ def mul_polys(a, b, root_of_unity):
     rc = _lib.lib().sh_mul_polys(_lib.ctx(), _lib.to_wire(a), len(a), _lib.to_wire(b), len(b), out, n,
                                  int(root_of_unity).to_bytes(32, "big"))
     _lib.check(rc, "sh_mul_polys")
-    return [field(x) for x in _lib.from_wire(out.raw)]
+    return _elements(field, _lib.from_wire(out.raw))
 
 
 def low_degree_extension(field, trace_columns, extension_factor, G2):
@@ -163,4 +169,4 @@ def low_degree_extension(field, trace_columns, extension_factor, G2):
     rc = _lib.lib().sh_lde(_lib.ctx(), data, out, steps, extension_factor, len(cols), int(G2).to_bytes(32, "big"))
     _lib.check(rc, "sh_lde")
     flat = _lib.from_wire(out.raw)
-    return [[field(x) for x in flat[c * n:(c + 1) * n]] for c in range(len(cols))]
+    return [_elements(field, flat[c * n:(c + 1) * n]) for c in range(len(cols))]

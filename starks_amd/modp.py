@@ -114,6 +114,17 @@ def IntegersModP(p):
         def to_bytes(self):
             return self.n.to_bytes(32, "big")  # modp.py:94-95
 
+        @classmethod
+        def wrap_canonical(cls, ints):
+            """Elements for values ALREADY in [0, p) -- what the device returns -- without the per-value type tests and the
+            `% p` of the constructor (about a tenth faster: creating 2^20 Python objects costs 0.4-0.5 s either way)."""
+            new, out = object.__new__, []
+            for x in ints:
+                e = new(cls)
+                e.n = x
+                out.append(e)
+            return out
+
     IntegerModP.p = p
     IntegerModP.m = 1
     IntegerModP.field_size = p
