@@ -343,3 +343,25 @@ def test_host_generality_outside_the_hot_path():
             for j, y in enumerate(b):
                 prod[(i + j) % order] = (prod[(i + j) % order] + x * y) % 31
         assert got == [(order * v) % 31 for v in prod]   # n * (a * b): the reference omits the 1/n (fft.py:345)
+
+
+def test_proof_stream_round_trips_on_random_shapes():
+    """compress_fri / compress_branches and their single-pass decoders (starks_amd/compression.py, format of
+    compression.py:1-101) on random nested proofs with many repeated nodes (back-references, repeated markers)."""
+    import random
+    from starks_amd import compression as cz
+    rng = random.Random(11)
+    pool = [rng.randbytes(32) for _ in range(12)]          # few distinct nodes: most objects become 2-byte references
+    for trial in range(60):
+        layers = []
+        for _ in range(rng.randrange(0, 4)):
+            yproofs = [[[rng.choice(pool) for _ in range(rng.randrange(0, 5))] for _ in range(rng.randrange(0, 4))]
+                       for _ in range(rng.randrange(1, 4))]
+            layers.append([rng.choice(pool), yproofs])
+        prf = layers + [[rng.choice(pool) for _ in range(rng.randrange(0, 6))]]
+        c = cz.compress_fri(prf)
+        assert cz.decompress_fri(c) == prf
+        assert all(len(x) in (2, 4, 32) for x in c)
+        branches = [[rng.choice(pool) for _ in range(rng.randrange(0, 6))] for _ in range(rng.randrange(0, 6))]
+        assert cz.decompress_branches(cz.compress_branches(branches)) == branches
+        assert cz.bin_length(c) == sum(len(x) + (1 if len(x) == 32 else 0) for x in c)
