@@ -530,12 +530,13 @@ def butterflies(stage, log_r):
     return out
 
 
-def build_stage(stage, log_r):
+def build_stage(stage, log_r, bf=None):
     Label.count = 0
     sched = Sched()
     for ins in prologue(stage, log_r):
         sched.emit(ins)
-    bf = butterflies(stage, log_r)
+    if bf is None:
+        bf = butterflies(stage, log_r)
     ver = [0] * 16            # version of x[m] (token "X<m>v<k>" = version k is final)
     for m in range(16):
         sched.tokens.add("X%dv0" % m)
@@ -890,7 +891,39 @@ def emit_inc(path):
     return stats
 
 
+def emit_group4(path):
+    """EXPERIMENT (tools/ilp/group_bench.hip, not part of the library): one register group of an LDS-resident tile -- four
+    elements per thread pinned to v[96:127], two levels = four MFMA butterflies, one fragment buffer, 70 temporaries -- so that
+    the kernel around it fits 128 VGPRs = four waves per SIMD: what would the butterflies cost at the VALU passes' occupancy?"""
+    global DATA0, FRAG_B, NTEMP
+    saved = (DATA0, FRAG_B, NTEMP)
+    DATA0, FRAG_B, NTEMP = 96, FRAG, 70
+    try:
+        bf = [(0, 2, 0, 2048, S_BASE), (1, 3, 4096, 6144, S_BASE), (0, 1, 8192, 10240, S_BASE), (2, 3, 8192, 10240, S_BASE)]
+        sched, _ = build_stage(1, 6, bf)
+        n = sum(i.nslots for i in sched.out if i.kind not in ("nop", "label"))
+        clob = ['"v%d"' % i for i in range(NTEMP)] + ['"s%d"' % i for i in range(S_CA, S_LAST)] + ['"vcc"', '"scc"']
+        L = ["// GENERATED by gen_bflyasm.py --group4 (experiment).  %d instruction slots, %d s_nop for 4 butterflies" % (n, sched.nops),
+             "typedef uint32_t shk_x8 __attribute__((ext_vector_type(8)));",
+             "__device__ __forceinline__ void shk_group4_asm(shk_x8 (&x)[4], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi, uint32_t rho) {",
+             "  asm volatile("]
+        for t in asm_text(sched):
+            L.append('      "%s\\n\\t"' % t)
+        L.append("      : " + ", ".join('"+{v[%d:%d]}"(x[%d])' % (DATA0 + 8 * m, DATA0 + 8 * m + 7, m) for m in range(4)))
+        L.append('      : [offs] "v"(offs), [lane16] "v"(lane16), [mlo] "s"(mlo), [mhi] "s"(mhi), [rho] "s"(rho)')
+        L.append("      : " + ", ".join(clob) + ");")
+        L.append("}")
+        with open(path, "w") as fh:
+            fh.write("\n".join(L) + "\n")
+        return n, sched.nops
+    finally:
+        DATA0, FRAG_B, NTEMP = saved
+
+
 if __name__ == "__main__":
+    if "--group4" in sys.argv:
+        print("group of 4 butterflies: %d slots, %d s_nop" % emit_group4(sys.argv[sys.argv.index("--group4") + 1]))
+        sys.exit(0)
     if "--selftest" in sys.argv:
         tot = 0
         for stage in (1, 2):
