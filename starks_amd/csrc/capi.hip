@@ -275,14 +275,16 @@ int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) 
 // Which kernels run the tile passes.  Default: the integer-VALU passes (ntt_kernels.cuh).  STARKHIP_NTT_PATH=mfma selects
 // the matrix-core passes (ntt_mfma.hip) wherever they apply: measured within +-8 % of the VALU passes on every shape
 // (DESIGN.md section 5), ahead on large batches, behind on single vectors -- kept selectable, not default.
-bool use_mfma_path() {
+// STARKHIP_NTT_PATH=mfma_lds: the LDS-resident 32-column tile with matrix-core register groups (ntt_mfma.hip, second half).
+int mfma_kind() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_NTT_PATH");
-    v = (e && !strcmp(e, "mfma")) ? 1 : 0;
+    v = (e && !strcmp(e, "mfma")) ? 1 : (e && !strcmp(e, "mfma_lds")) ? 2 : 0;
   }
-  return v == 1;
+  return v;
 }
+bool use_mfma_path() { return mfma_kind() != 0; }
 
 int tw2_max_log() {
   static int v = -1;
@@ -379,7 +381,8 @@ void choose_radices(int log_n, bool few, std::vector<int>* out) {
     if (log_n == 19) { *out = {9, 10}; return; }
     if (log_n == 20) { *out = {10, 10}; return; }
   }
-  const int m = (log_n + 7) / 8, base = log_n / m, rem = log_n % m;
+  const int top = (mfma_kind() == 2 && log_n <= 28) ? 7 : 8;  // the LDS-resident matrix-core tile holds at most 2^7 rows
+  const int m = (log_n + top - 1) / top, base = log_n / m, rem = log_n % m;
   for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));
 }
 
@@ -580,7 +583,7 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
   const uint64_t n = pl->n;
   if (batch == 0) return SH_OK;
   if (n_in >= n) n_in = 0;
-  if (n_in && (pl->log_n <= 1 || (use_mfma_path() && pl->radix[0] >= 5))) {  // paths without the short-source load
+  if (n_in && (pl->log_n <= 1 || (mfma_kind() == 1 && pl->radix[0] >= 5))) {  // paths without the short-source load
     HIP_TRY(c, shk_pad_copy(d_in, d_out, n_in, n, batch, c->stream));
     d_in = d_out;
     n_in = 0;
@@ -627,6 +630,7 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
       a.scale = (m == 1) ? pl->scale : nullptr;
     }
     a.mats = use_mfma_path() ? pl->mats[d] : nullptr;
+    a.mfma_kind = (uint32_t)mfma_kind();
 #ifdef SHK_STAMPS
     {
       const char* e = getenv("STARKHIP_STAMP_PASS");
@@ -1489,7 +1493,7 @@ uint32_t sh_ntt_passes(uint64_t n, uint32_t batch) {
   return (uint32_t)r.size();
 }
 
-const char* sh_ntt_path_name(void) { return use_mfma_path() ? "mfma" : "valu"; }
+const char* sh_ntt_path_name(void) { return mfma_kind() == 2 ? "mfma_lds" : mfma_kind() == 1 ? "mfma" : "valu"; }
 
 uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
   return fri_proof_len(n, maxdeg_plus_1, samples);

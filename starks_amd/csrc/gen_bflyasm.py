@@ -416,6 +416,9 @@ def stream_F(j, base_sreg, off1, off2, need, both, fr=FRAG):
     L = []
 
     def addr(dst, off):
+        if isinstance(off, str):   # byte offset in an asm operand (an SGPR): register groups of the LDS-resident tile
+            return I(["s_add_u32 s%d, s%d, %%[%s]" % (dst, base_sreg, off), "s_addc_u32 s%d, s%d, 0" % (dst + 1, base_sreg + 1)],
+                     "salu", [], ["scc", "s%d" % dst], ("saddr_op", dst, base_sreg, off))
         return I(["s_add_u32 s%d, s%d, 0x%x" % (dst, base_sreg, off), "s_addc_u32 s%d, s%d, 0" % (dst + 1, base_sreg + 1)], "salu",
                  [], ["scc", "s%d" % dst], ("saddr", dst, base_sreg, off))
 
@@ -653,6 +656,7 @@ class Sim(object):
         O = offs_block()
         self.offs = [[O[l >> 5][r] for l in range(64)] for r in range(16)]
         self.inflight = []
+        self.operands = {}
 
     def v(self, r):
         return self.V[r]
@@ -768,6 +772,9 @@ class Sim(object):
             elif sm[0] == "saddr":
                 _, dst, base, off = sm
                 self.S[dst] = self.S[base] + off
+            elif sm[0] == "saddr_op":
+                _, dst, base, opname = sm
+                self.S[dst] = self.S[base] + self.operands[opname]
             elif sm[0] == "load":
                 _, dreg, areg, imm, _tag = sm
                 vals = {}
@@ -891,6 +898,155 @@ def emit_inc(path):
     return stats
 
 
+# ---- register groups of an LDS-resident tile (ntt_kernels.cuh with MFMA butterflies) -------------------------------------------
+# Four elements per thread (x[h] pinned to v[96 + 8 h ..]), two DIF levels = up to four butterflies.  The twiddle of a butterfly
+# is the same for the 32 lanes of a half-wave (they are the 32 columns of one row); the kernel passes the byte offsets of the two
+# TwMat images (lanes 0..31 / 32..63) of every MFMA butterfly as scalar operands o<k>lo / o<k>hi.
+GROUP_PATTERNS = {
+    # name: [(m0, m1, kind)], kind "M" = MFMA butterfly with a table twiddle, "A" = twiddle 1 (add / sub)
+    "MMMM": [(0, 2, "M"), (1, 3, "M"), (0, 1, "M"), (2, 3, "M")],   # both levels general
+    "AMAA": [(0, 2, "A"), (1, 3, "M"), (0, 1, "A"), (2, 3, "A")],   # the last two levels of a tile: 1, w^(R/4), 1, 1
+    "AA": [(0, 1, "A"), (2, 3, "A")],                               # a single last level (odd log R)
+    "MM": [(0, 1, "M"), (2, 3, "M")],                               # a single general level
+}
+
+
+def with_group_layout(fn):
+    def wrapped(*a, **k):
+        global DATA0, FRAG_B, NTEMP
+        saved = (DATA0, FRAG_B, NTEMP)
+        DATA0, FRAG_B, NTEMP = 96, FRAG, 70
+        try:
+            return fn(*a, **k)
+        finally:
+            DATA0, FRAG_B, NTEMP = saved
+    return wrapped
+
+
+@with_group_layout
+def build_group(pattern):
+    """the scheduled block of one register group; returns (sched, butterfly list [(m0, m1, slot or None)])"""
+    Label.count = 0
+    sched = Sched()
+    for ins in prologue(2, 0):   # constants + base = the TwMat table
+        sched.emit(ins)
+    bf = []
+    slot = 0
+    for (m0, m1, kind) in GROUP_PATTERNS[pattern]:
+        if kind == "M":
+            bf.append((m0, m1, "o%dlo" % slot, "o%dhi" % slot, S_BASE))
+            slot += 1
+        else:
+            bf.append((m0, m1, None, None, S_BASE))
+    ver = [0] * 16
+    for m in range(16):
+        sched.tokens.add("X%dv0" % m)
+    streams = []
+    prev_mf = prev_as = None
+    for j, (m0, m1, off1, off2, base) in enumerate(bf):
+        need_x = ["X%dv%d" % (m0, ver[m0]), "X%dv%d" % (m1, ver[m1])]
+        if j:
+            need_x.append("SUM%d" % (j - 1))
+        ver[m0] += 1
+        ver[m1] += 1
+        give_a, give_b = ["X%dv%d" % (m0, ver[m0])], ["X%dv%d" % (m1, ver[m1])]
+        if off1 is None:
+            # the difference is built in the fragment registers (no second buffer in this layout): not while an MFMA
+            # butterfly's fragments live there
+            streams.append(((j, 0), stream_AS(sched, j, m0, m1, need_x + (["M%d" % prev_mf] if prev_mf is not None else []),
+                                              give_a + give_b)))
+            prev_as = j
+            continue
+        streams.append(((j, 1), stream_P(sched, j, m0, m1, need_x + (["M12_%d" % prev_mf] if prev_mf is not None else []), give_a)))
+        streams.append(((j, -1), stream_F(j, base, off1, off2, (["M%d" % prev_mf] if prev_mf is not None else []) +
+                                          (["SUM%d" % prev_as] if prev_as is not None else []), True, FRAG)))
+        streams.append(((j, 2), stream_M(j, m1, True, ["P%d" % j] + (["ACC%d" % prev_mf] if prev_mf is not None else []), fr=FRAG)))
+        n = stream_N(j)
+        n[0].need = ("M%d" % j,)
+        streams.append(((j, 3), n))
+        jj = stream_J(sched, j, m1, give_b)
+        jj[0].need = ("N%d" % j,)
+        streams.append(((j, 4), jj))
+        prev_mf = j
+    sched.run(streams)
+    sched.emit(I("s_nop 1", "nop"))
+    return sched, bf
+
+
+@with_group_layout
+def selftest_group(pattern, seed=1, crafted=False):
+    rng = random.Random(seed * 77 + len(pattern))
+    sched, bf = build_group(pattern)
+    R = 64
+    wR = pow(7, (P - 1) // R, P)
+    tw = [pow(wR, i, P) for i in range(R // 2)]
+    mats_addr = 0x10000
+    mem = bytearray(mats_addr) + b"".join(twmat_bytes(t) for t in tw)
+    st = Sim(mem, mats_addr, 0)
+    choice = {}
+    for (m0, m1, o1, o2, base) in bf:
+        if o1 is not None:
+            choice[o1], choice[o2] = rng.randrange(R // 2), rng.randrange(R // 2)
+            st.operands[o1], st.operands[o2] = 2048 * choice[o1], 2048 * choice[o2]
+    vals = [[rng.randrange(2**256) for _ in range(64)] for _ in range(4)]
+    if crafted:
+        for m in range(4):
+            for l in range(64):
+                c = rng.randrange(6)
+                if c == 0:
+                    vals[m][l] = 2**256 - 1 - rng.randrange(4)
+                elif c == 1:
+                    vals[m][l] = rng.randrange(4)
+                elif c == 2:
+                    vals[m][l] = P - 1 - rng.randrange(3)
+    for m in range(4):
+        for i in range(8):
+            st.V[X(m, i)] = [(vals[m][l] >> (32 * i)) & M32 for l in range(64)]
+    st.run(sched)
+    ref = [list(v) for v in vals]
+    for (m0, m1, o1, o2, base) in bf:
+        for l in range(64):
+            w = 1 if o1 is None else tw[choice[o2 if l >= 32 else o1]]
+            a, b = ref[m0][l], ref[m1][l]
+            ref[m0][l] = (a + b) % P
+            ref[m1][l] = (a - b) * w % P
+    bad = sum(1 for m in range(4) for l in range(64)
+              if sum(st.V[X(m, i)][l] << (32 * i) for i in range(8)) % P != ref[m][l])
+    return bad, sched
+
+
+@with_group_layout
+def emit_groups(path):
+    """mfma_group.inc: the group blocks by pattern"""
+    clob = ['"v%d"' % i for i in range(NTEMP)] + ['"s%d"' % i for i in range(S_CA, S_LAST)] + ['"vcc"', '"scc"']
+    L = ["// GENERATED by gen_bflyasm.py -- do not edit.  Register groups of the LDS-resident tile pass with matrix-core butterflies:",
+         "// x[h] pinned to v[96 + 8 h : 103 + 8 h]; v0..v%d, s%d..s%d, vcc and scc clobbered; o<k>lo / o<k>hi = byte offsets of the TwMat" % (NTEMP - 1, S_CA, S_LAST - 1),
+         "// images (mfma_tw.cuh) of the k-th MFMA butterfly for lanes 0..31 / 32..63.",
+         "#define SHK_GROUP_CLOBBERS " + ", ".join(clob)]
+    stats = []
+    for name in ("MMMM", "AMAA", "AA", "MM"):
+        sched, bf = build_group(name)
+        n = sum(i.nslots for i in sched.out if i.kind not in ("nop", "label"))
+        nm = sum(1 for b in bf if b[2] is not None)
+        stats.append((name, n, sched.nops))
+        args = "shk_x8 (&x)[4], const shk_v16i& offs, uint32_t lane16, uint32_t mlo, uint32_t mhi" + \
+            "".join(", uint32_t o%dlo, uint32_t o%dhi" % (k, k) for k in range(nm))
+        L.append("// pattern %s: %d instruction slots, %d s_nop" % (name, n, sched.nops))
+        L.append("__device__ __forceinline__ void shk_group_asm_%s(%s) {" % (name, args))
+        L.append("  asm volatile(")
+        for t in asm_text(sched):
+            L.append('      "%s\\n\\t"' % t)
+        L.append("      : " + ", ".join('"+{v[%d:%d]}"(x[%d])' % (DATA0 + 8 * m, DATA0 + 8 * m + 7, m) for m in range(4)))
+        ins = '[offs] "v"(offs), [lane16] "v"(lane16), [mlo] "s"(mlo), [mhi] "s"(mhi)' + \
+            "".join(', [o%dlo] "s"(o%dlo), [o%dhi] "s"(o%dhi)' % (k, k, k, k) for k in range(nm))
+        L.append("      : " + ins)
+        L.append("      : SHK_GROUP_CLOBBERS);")
+        L.append("}")
+    with open(path, "w") as fh:
+        fh.write("\n".join(L) + "\n")
+    return stats
+
+
 def emit_group4(path):
     """EXPERIMENT (tools/ilp/group_bench.hip, not part of the library): one register group of an LDS-resident tile -- four
     elements per thread pinned to v[96:127], two levels = four MFMA butterflies, one fragment buffer, 70 temporaries -- so that
@@ -931,7 +1087,14 @@ if __name__ == "__main__":
                 for crafted in (False, True):
                     b, _ = selftest(stage, log_r, crafted=crafted, verbose=True)
                     tot += b
+        for name in GROUP_PATTERNS:
+            for crafted in (False, True):
+                b, sc = selftest_group(name, crafted=crafted)
+                print("group %s%s: %d s_nop, mismatches %d" % (name, " (crafted)" if crafted else "", sc.nops, b))
+                tot += b
         sys.exit(1 if tot else 0)
     here = os.path.dirname(os.path.abspath(__file__))
     for st in emit_inc(os.path.join(here, "mfma_bfly.inc")):
         print("stage %d R=2^%d: %d slots, %d s_nop, %d butterflies" % st)
+    for st in emit_groups(os.path.join(here, "mfma_group.inc")):
+        print("group %s: %d slots, %d s_nop" % st)

@@ -134,10 +134,18 @@ __device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
   }
 }
 
+// The butterflies of a register group on the VALUs (this file) or, for tiles 32 columns wide, on the matrix cores
+// (ntt_mfma.hip: MfmaLane, whose butterflies() replaces the arithmetic below; everything else of the pass is shared).
+struct ValuLane {
+  static constexpr bool mfma = false;
+  __device__ __forceinline__ void stamp(int) const {}  // phase stamps of the diagnostic build (ntt_mfma.hip)
+};
+
 // Register group g: fetch 4 elements (global memory for g == 0, LDS otherwise), do its butterfly levels,
 // and hand the elements to the next group through LDS.
-template <int LOG_R, int LOG_T, bool LAST, int g>
-__device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, TileThread& th, uint32_t tid, uint64_t tile0) {
+template <int LOG_R, int LOG_T, bool LAST, int g, class LANE>
+__device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, TileThread& th, uint32_t tid, uint64_t tile0,
+                                          const LANE& ln) {
   constexpr int R = 1 << LOG_R;
   constexpr int T = 1 << LOG_T;
   constexpr int G = (LOG_R + 1) / 2;
@@ -209,7 +217,8 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   };
   // one twiddle is always in flight: the first is requested before the elements are fetched, the next before the current
   // product (the product's inline asm keeps the compiler from moving loads across it, so source order is issue order)
-  constexpr int first_tw = tw_needed(0) ? 0 : tw_needed(1) ? 1 : tw_needed(2) ? 2 : tw_needed(3) ? 3 : 4;
+  constexpr bool on_mfma = LANE::mfma && !rfast;  // the row pass's first group has a row per lane: its twiddles differ per lane
+  constexpr int first_tw = on_mfma ? 4 : tw_needed(0) ? 0 : tw_needed(1) ? 1 : tw_needed(2) ? 2 : tw_needed(3) ? 3 : 4;
   fp2 tw_cur, tw_nxt;
   if constexpr (first_tw < 4) tw_cur = tw_load(first_tw);
 
@@ -225,6 +234,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
       th.x[0] = th.x[1] = th.x[2] = th.x[3] = fp_zero();
       if (FP_ANY(in)) {  // wave-uniform
         fp x0 = fp_load(a.src + th.sbase + (in ? off : 0));
+        if constexpr (on_mfma) tw_cur = tw_load(0);
         const fp2 tw_b = tw_load(2), tw_c = tw_load(3);  // tw_cur holds butterfly 0's
 #pragma unroll
         for (int w = 0; w < 8; ++w) x0.v[w] = in ? x0.v[w] : 0u;
@@ -265,7 +275,9 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   }
 
   // ---- butterfly levels (DIF: a' = a + b, b' = (a - b) * w^((i mod half) * 2^s)) ---------------------
-  if (!sparse_done) static_for4([&](auto bc) {
+  if constexpr (on_mfma) {
+    if (!sparse_done) ln.template butterflies<LOG_R, g>(th);
+  } else if (!sparse_done) static_for4([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     constexpr int q = qhi - (b >> 1), pr = b & 1;
     if constexpr (q >= 0) {
@@ -307,8 +319,8 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 #ifndef SHK_NTT_MIN_WAVES
 #define SHK_NTT_MIN_WAVES 4
 #endif
-template <int LOG_R, int LOG_T, bool LAST>
-__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) ntt_pass_kernel(NttPassArgs a) {
+template <int LOG_R, int LOG_T, bool LAST, class LANE>
+__device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& ln) {
   static_assert(LOG_R >= 2 && LOG_R <= 11 && LOG_T >= 0 && LOG_R + LOG_T >= 8 && LOG_R + LOG_T <= 12, "unsupported tile");
   constexpr int G = (LOG_R + 1) / 2;  // register groups (two levels each, the last may have one)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -328,6 +340,7 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
     }
   }
   const uint64_t tile0 = tile << LOG_T;
+  ln.stamp(0);
   TileThread th;
   th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0; th.sbase = 0;
   // Column passes: the inter-pass twiddles g^(j2 k) of this thread's outputs are requested ahead of their use -- before the
@@ -342,32 +355,39 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
     return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
   };
   auto itw_request = [&]() {
-    if (!LAST && a.tw2) {
+    if (!LAST && a.tw2 && !LANE::mfma) {  // (a matrix-core group leaves no registers for it)
       itw[0] = itw_load(0);
     }
   };
   if constexpr (G == 1) {
-    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
+    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0, ln);
+    ln.stamp(1);
     itw_request();
   } else {
-    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
+    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0, ln);
+    ln.stamp(1);
     if constexpr (G == 2) itw_request();
-    ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
+    ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0, ln);
+    ln.stamp(2);
     if constexpr (G > 2) {
       if constexpr (G == 3) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
+      ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0, ln);
+      ln.stamp(3);
     }
     if constexpr (G > 3) {
       if constexpr (G == 4) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0);
+      ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0, ln);
+      ln.stamp(4);
     }
     if constexpr (G > 4) {
       if constexpr (G == 5) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0);
+      ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0, ln);
+      ln.stamp(5);
     }
     if constexpr (G > 5) {
       if constexpr (G == 6) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0);
+      ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0, ln);
+      ln.stamp(6);
     }
   }
 
@@ -382,12 +402,19 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
       if (a.scale) v = fp_mul(v, fp_load(a.scale));
       fp_store(a.dst + th.obase + ((uint64_t)k << a.log_P), v);
     } else {
+      if (LANE::mfma && a.tw2 && h == 0) itw[0] = itw_load(0);
       if (a.tw2 && h + 1 < 4) itw[h + 1] = itw_load(h + 1);
       const fp tw = a.tw2 ? itw[h] : tw_lookup(a, th.j2 * k);
       fp v = fp_mul(th.x[h], tw);
       fp_store(a.dst + th.gbase + ((uint64_t)k << a.log_S), v);
     }
   }
+  ln.stamp(G + 1);
+}
+
+template <int LOG_R, int LOG_T, bool LAST>
+__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) ntt_pass_kernel(NttPassArgs a) {
+  ntt_pass_body<LOG_R, LOG_T, LAST>(a, ValuLane{});
 }
 
 // n <= 2: the reference's naive base case (_simple_ft, fft.py:287-300) is the whole transform.

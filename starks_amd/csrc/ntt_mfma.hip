@@ -30,6 +30,7 @@
 #include "ntt_kernels.cuh"
 #include "ntt_tile_common.cuh"
 #include "mfma_bfly.inc"  // GENERATED (gen_bflyasm.py): the two butterfly stages as scheduled asm blocks
+#include "mfma_group.inc"  // GENERATED (gen_bflyasm.py): the register groups of the LDS-resident 32-column tile
 
 #ifdef SHK_STAMPS
 // diagnostic build only (make STAMPS=1 -> libstarkhip_stamps.so): s_memtime at the phase boundaries of wave 0 of the
@@ -323,6 +324,106 @@ hipError_t launch_ctile(const NttPassArgs& a, hipStream_t st) {
   return use_asm_butterflies() ? launch_ctile_impl<LOG_R, LAST, true>(a, st) : launch_ctile_impl<LOG_R, LAST, false>(a, st);
 }
 
+// ---- the LDS-resident tile of ntt_kernels.cuh, 32 columns wide, with its register groups' butterflies on the matrix cores ------
+// Same pass, same lane mapping (four elements per thread, two levels per LDS exchange, R x 32 elements in LDS) -- but the 32
+// lanes of a half-wave are the 32 columns of one row set, so a butterfly's twiddle is one matrix per half-wave and the
+// group's arithmetic is one generated block (mfma_group.inc) on 128 VGPRs: four waves per SIMD, twice the register-tile
+// kernel above.  The row pass's first group (a row per lane) and the sparse first group of the low-degree extension stay
+// on the VALU butterflies.
+struct MfmaLane {
+  static constexpr bool mfma = true;
+  shk_v16i offs;
+  uint32_t lane16, mlo, mhi;
+#ifdef SHK_STAMPS
+  uint32_t debug;
+  __device__ __forceinline__ void stamp(int k) const {
+    if (debug && threadIdx.x == 0 && blockIdx.x < 1024) g_stamps[k][blockIdx.x] = __builtin_amdgcn_s_memtime();
+  }
+#else
+  __device__ __forceinline__ void stamp(int) const {}
+#endif
+
+  template <int LOG_R, int g>
+  __device__ __forceinline__ void butterflies(TileThread& th) const {
+    constexpr int G = (LOG_R + 1) / 2;
+    constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;
+    shk_x8 xv[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xv[h][i] = th.x[h].v[i];
+    if constexpr (beta > 0) {
+      // levels q = beta + 1 (pairs (0,2), (1,3): exponents (low | pr << beta) << (LOG_R - 2 - beta)) and q = beta (pairs
+      // (0,1), (2,3): low << (LOG_R - 1 - beta) for both), low = the row bits below the group's two
+      static_assert(g < G - 1, "");
+      const uint32_t low = th.ibase & ((1u << beta) - 1u);
+      const uint32_t e0 = (low << (LOG_R - 2 - beta)) * (uint32_t)sizeof(TwMat);
+      const uint32_t e1 = ((low | (1u << beta)) << (LOG_R - 2 - beta)) * (uint32_t)sizeof(TwMat);
+      const uint32_t e2 = (low << (LOG_R - 1 - beta)) * (uint32_t)sizeof(TwMat);
+      const uint32_t o0l = __builtin_amdgcn_readfirstlane(e0), o0h = __builtin_amdgcn_readlane(e0, 32);
+      const uint32_t o1l = __builtin_amdgcn_readfirstlane(e1), o1h = __builtin_amdgcn_readlane(e1, 32);
+      const uint32_t o2l = __builtin_amdgcn_readfirstlane(e2), o2h = __builtin_amdgcn_readlane(e2, 32);
+      shk_group_asm_MMMM(xv, offs, lane16, mlo, mhi, o0l, o0h, o1l, o1h, o2l, o2h, o2l, o2h);
+    } else if constexpr (LOG_R % 2 == 0) {
+      constexpr uint32_t o = (uint32_t)((1u << LOG_R) / 4) * (uint32_t)sizeof(TwMat);  // 1, w^(R/4); then 1, 1
+      shk_group_asm_AMAA(xv, offs, lane16, mlo, mhi, o, o);
+    } else {
+      shk_group_asm_AA(xv, offs, lane16, mlo, mhi);
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) th.x[h].v[i] = xv[h][i];
+  }
+};
+
+template <int LOG_R, bool LAST>
+__global__ void __launch_bounds__(8 << LOG_R) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_ltile_kernel(NttPassArgs a) {
+  static_assert(LOG_R >= 5 && LOG_R <= 7, "unsupported radix");
+  MfmaLane ln;
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ln.offs[r] = (lane >> 5) ? SHK_OFFS[1][r] : SHK_OFFS[0][r];
+  ln.lane16 = lane * 16u;
+  ln.mlo = (uint32_t)reinterpret_cast<uintptr_t>(a.mats);
+  ln.mhi = (uint32_t)(reinterpret_cast<uintptr_t>(a.mats) >> 32);
+#ifdef SHK_STAMPS
+  ln.debug = a.debug;
+#endif
+  ntt_pass_body<LOG_R, 5, LAST>(a, ln);
+}
+
+template <int LOG_R, bool LAST>
+hipError_t launch_ltile(const NttPassArgs& a, hipStream_t st) {
+  constexpr size_t LDS = (size_t)32 << (LOG_R + 5);
+  auto k = ntt_ltile_kernel<LOG_R, LAST>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    if (e != hipSuccess) return e;
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  const uint64_t tiles = (a.total + 31) >> 5;
+  if (tiles == 0) return hipSuccess;
+  if (tiles > 0x7fffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(8u << LOG_R), LDS, st, a);
+  return hipGetLastError();
+}
+
+template <bool LAST>
+hipError_t dispatch_ltile(int log_R, const NttPassArgs& a, hipStream_t st) {
+  switch (log_R) {
+    case 5: return launch_ltile<5, LAST>(a, st);
+    case 6: return launch_ltile<6, LAST>(a, st);
+    case 7: return launch_ltile<7, LAST>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <bool LAST>
 hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
   switch (log_R) {
@@ -337,11 +438,13 @@ hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
 }  // namespace
 
 bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a) {
+  if (a.mfma_kind == 2) return a.mats && log_R >= 5 && log_R <= 7 && (last || a.log_S >= 5);
   if (log_R < 5 || log_R > 8 || !a.mats) return false;
   if (!last && (a.log_S < 5 || !a.tw2)) return false;  // a tile's 32 columns must be adjacent
   return true;
 }
 
 hipError_t shk_launch_ntt_pass_mfma(int log_R, bool last, const NttPassArgs& a, hipStream_t st) {
+  if (a.mfma_kind == 2) return last ? dispatch_ltile<true>(log_R, a, st) : dispatch_ltile<false>(log_R, a, st);
   return last ? dispatch<true>(log_R, a, st) : dispatch<false>(log_R, a, st);
 }

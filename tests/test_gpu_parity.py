@@ -1068,12 +1068,14 @@ def test_bench_two_ranks_share_this_gpu(sa, args):
         assert line["scaling"] == "strong" and line["unit"] == "proofs/s"
 
 
-def test_mfma_tile_passes_parity(sa, tmp_path):
-    """The matrix-core tile passes (csrc/ntt_mfma.hip, STARKHIP_NTT_PATH=mfma; the default is the integer-VALU passes):
-    the NTT golden vectors, every size against the oracle, the 2^22 digest and a FRI + STARK proof, in a child process."""
+@pytest.mark.parametrize("path", ["mfma", "mfma_lds"])
+def test_mfma_tile_passes_parity(sa, tmp_path, path):
+    """The matrix-core tile passes (csrc/ntt_mfma.hip; the default is the integer-VALU passes) -- STARKHIP_NTT_PATH=mfma: the
+    tile in registers; mfma_lds: the LDS-resident 32-column tile with generated register groups: the NTT golden vectors, every
+    size against the oracle, the 2^22 digest and a FRI + STARK proof, in a child process."""
     import subprocess, sys
     from conftest import ROOT
-    env = dict(os.environ, STARKHIP_NTT_PATH="mfma")
+    env = dict(os.environ, STARKHIP_NTT_PATH=path)
     sel = ("test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or "
            "test_randomized_ntt_differential or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or "
            "test_fri_proofs_golden or test_stark_proofs_golden or test_device_resident_pipeline")

@@ -312,6 +312,16 @@ def test_generated_mfma_stages_simulate_correctly():
         g.emit_inc(out)
         assert open(out).read() == open(os.path.join(ROOT, "starks_amd", "csrc", "mfma_bfly.inc")).read(), \
             "mfma_bfly.inc is stale: run python3 starks_amd/csrc/gen_bflyasm.py"
+    # the register groups of the LDS-resident tile (mfma_group.inc): every pattern, twiddles chosen per half-wave
+    for name in g.GROUP_PATTERNS:
+        for crafted in (False, True):
+            bad, sched = g.selftest_group(name, crafted=crafted)
+            assert bad == 0, (name, crafted)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "mfma_group.inc")
+        g.emit_groups(out)
+        assert open(out).read() == open(os.path.join(ROOT, "starks_amd", "csrc", "mfma_group.inc")).read(), \
+            "mfma_group.inc is stale: run python3 starks_amd/csrc/gen_bflyasm.py"
 
 
 def test_host_generality_outside_the_hot_path():
