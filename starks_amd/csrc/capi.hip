@@ -276,11 +276,12 @@ int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) 
 // the matrix-core passes (ntt_mfma.hip) wherever they apply: measured within +-8 % of the VALU passes on every shape
 // (DESIGN.md section 5), ahead on large batches, behind on single vectors -- kept selectable, not default.
 // STARKHIP_NTT_PATH=mfma_lds: the LDS-resident 32-column tile with matrix-core register groups (ntt_mfma.hip, second half).
+// STARKHIP_NTT_PATH=hybrid: the VALU plans and tiles, the groups whose twiddles are lane-shared on the matrix cores.
 int mfma_kind() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_NTT_PATH");
-    v = (e && !strcmp(e, "mfma")) ? 1 : (e && !strcmp(e, "mfma_lds")) ? 2 : 0;
+    v = (e && !strcmp(e, "mfma")) ? 1 : (e && !strcmp(e, "mfma_lds")) ? 2 : (e && !strcmp(e, "hybrid")) ? 3 : 0;
   }
   return v;
 }
@@ -370,7 +371,7 @@ void choose_radices(int log_n, bool few, std::vector<int>* out) {
   // tiles (one inter-pass twiddle modmul and one read + write of the vector fewer per transform;
   // everything from 2^21 up measured behind).  The matrix-core passes have no such radices: under
   // STARKHIP_NTT_PATH=mfma the three-pass decomposition stays.
-  if (!use_mfma_path()) {
+  if (mfma_kind() == 0 || mfma_kind() == 3) {
     // measured with the final kernels (wave-local exchanges), forward + inverse, against the three-pass plans of 1024-element
     // tiles: 2^20 12.3 / 14.1 / 14.5 / 15.5 / 16.1 / 16.5 vs 10.6 / 13.0 / 14.7 / 15.2 / 15.6 / 15.9 G elements/s at 1 / 2 / 4 / 8 / 16 / 32
     // vectors; 2^18 (9, 9) 14.4 / 17.0 / 18.2 vs 14.3 / 16.7 / 17.7 at 8 / 32 / 128.  `few` (a call of at most 2^21 elements) no
@@ -520,7 +521,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         wr_by_radix[r] = reinterpret_cast<const fp2*>(dev);
         mats_by_radix[r] = nullptr;
         // operand images for the matrix-core butterflies (ntt_mfma.hip), only when those passes are selected
-        if (rc == SH_OK && r >= 5 && r <= 8 && use_mfma_path()) {
+        if (rc == SH_OK && r >= 5 && r <= (mfma_kind() == 3 ? 11 : 8) && use_mfma_path()) {
           std::vector<TwMat> mm(t.size());
           for (size_t i = 0; i < t.size(); ++i)
             if (!shk_build_twmat(t[i], &mm[i])) rc = SH_ERR_INVALID;
@@ -1493,7 +1494,10 @@ uint32_t sh_ntt_passes(uint64_t n, uint32_t batch) {
   return (uint32_t)r.size();
 }
 
-const char* sh_ntt_path_name(void) { return mfma_kind() == 2 ? "mfma_lds" : mfma_kind() == 1 ? "mfma" : "valu"; }
+const char* sh_ntt_path_name(void) {
+  static const char* const names[] = {"valu", "mfma", "mfma_lds", "hybrid"};
+  return names[mfma_kind()];
+}
 
 uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
   return fri_proof_len(n, maxdeg_plus_1, samples);

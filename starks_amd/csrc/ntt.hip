@@ -7,58 +7,12 @@
 
 namespace {
 
-// Tiles narrower than 128 bytes (T < 4: the big-radix passes) share their cache lines with the neighbouring tile; workgroups
-// are dealt to the 8 XCDs round-robin, so neighbours would sit behind different L2s and every line would be fetched (or
-// written back partially) twice.  Default (1): such launches map adjacent tiles to the same XCD (measured on the T = 1
-// variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ: 0 = never, 2 = every tile pass (measured level for T >= 4),
-// 3 = as 1 plus the sharer-fastest order below.
-int xcd_swizzle() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("STARKHIP_XCD_SWZ");
-    v = e ? atoi(e) : 1;
-    if (v < 0 || v > 3) v = 0;
-  }
-  return v;
-}
-
 template <int LOG_R, bool LAST, int TILE_LOG>
 hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
   constexpr int LOG_T = TILE_LOG - LOG_R;
-  constexpr int THREADS = 1 << (TILE_LOG - 2);
-  constexpr size_t LDS = (size_t)32 << TILE_LOG;
-  auto k = ntt_pass_kernel<LOG_R, LOG_T, LAST>;
-  // the attribute is per device: one bit per device ordinal, per instantiation (contexts on several devices, and on
-  // several host threads, share this function)
   static std::atomic<uint64_t> attr_done{0};
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  const uint64_t bit = 1ull << (dev & 63);
-  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-    if (e != hipSuccess) return e;
-    attr_done.fetch_or(bit, std::memory_order_release);
-  }
-  const uint64_t tiles = (a.total + ((1ull << LOG_T) - 1)) >> LOG_T;
-  if (tiles == 0) return hipSuccess;
-  if (tiles > 0x7ffffff0ull) return hipErrorInvalidValue;
-  NttPassArgs b = a;
-  uint64_t grid = tiles;
-  // column passes whose twiddle rows (tw2) are shared by several vectors / prefix blocks: sharer-fastest order, XCD-local.
-  // Opt-in only (STARKHIP_XCD_SWZ=3): it removes the per-vector re-fetch of the rows (2 * FETCH_SIZE of the 2^20 x 8 column
-  // pass 540 -> 325 MB) but measured 3-8 % SLOWER -- the sharers sit 2^k bytes apart, so the concurrently running tiles
-  // all map to the same memory channels.
-  const uint64_t sharers = LAST ? 0 : (a.total >> a.log_S);
-  const bool share = !LAST && a.tw2 && sharers >= 2 && sharers <= 0xffffffffull && a.log_S >= (uint32_t)LOG_T + 2 &&
-                     tiles <= 0xffffffffull && xcd_swizzle() == 3;
-  if (xcd_swizzle() && (xcd_swizzle() == 2 || LOG_T < 2 || share) && tiles >= 64) {
-    b.xcd_per = (uint32_t)((tiles + 7) / 8);
-    b.sharers = share ? (uint32_t)sharers : 0;
-    grid = 8ull * b.xcd_per;
-  }
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(THREADS), LDS, st, b);
-  return hipGetLastError();
+  return shk_launch_tile_kernel(ntt_pass_kernel<LOG_R, LOG_T, LAST>, attr_done, LOG_T, 1u << (TILE_LOG - 2), (size_t)32 << TILE_LOG,
+                                LAST, a, st);
 }
 
 int tile_log_choice() {

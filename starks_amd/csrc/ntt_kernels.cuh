@@ -14,6 +14,9 @@
 // w^(n/R) shared by every pass that uses radix R; the bit-reversed order DIF leaves is undone by the
 // store addresses.  The last two levels of each tile transform have twiddles 1 / w^(R/4) only.
 #pragma once
+#include <stdlib.h>
+
+#include <atomic>
 #include <type_traits>
 
 #include "internal.hpp"
@@ -134,10 +137,17 @@ __device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
   }
 }
 
-// The butterflies of a register group on the VALUs (this file) or, for tiles 32 columns wide, on the matrix cores
-// (ntt_mfma.hip: MfmaLane, whose butterflies() replaces the arithmetic below; everything else of the pass is shared).
+// Who does the butterflies of a register group, and which thread holds which elements there: the VALUs with the mapping above
+// (this file), or -- for groups whose twiddles are shared by the 32 lanes of a half-wave -- the matrix cores (ntt_mfma.hip:
+// MfmaLane / HybridLane, whose butterflies() replaces the arithmetic below; everything else of the pass is shared).
 struct ValuLane {
-  static constexpr bool mfma = false;
+  static constexpr bool itw_prefetch = true;  // the first inter-pass twiddle is requested ahead of the last group
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr bool group_on_mfma(int) { return false; }
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr int phase(int g) { return tile_phase<LOG_R, LOG_T, LAST>(g); }
+  template <int LOG_R, int LOG_T, bool LAST, int g>
+  static __device__ __forceinline__ uint32_t ibase(uint32_t tid) { return tile_ibase<LOG_R, LOG_T, g>(tid); }
   __device__ __forceinline__ void stamp(int) const {}  // phase stamps of the diagnostic build (ntt_mfma.hip)
 };
 
@@ -157,7 +167,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     th.ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
   } else {
     th.t = tid & (T - 1);
-    th.ibase = tile_ibase<LOG_R, LOG_T, g>(tid);
+    th.ibase = LANE::template ibase<LOG_R, LOG_T, LAST, g>(tid);
   }
 
   if (g == 0 || (LAST && g == 1)) {
@@ -217,7 +227,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   };
   // one twiddle is always in flight: the first is requested before the elements are fetched, the next before the current
   // product (the product's inline asm keeps the compiler from moving loads across it, so source order is issue order)
-  constexpr bool on_mfma = LANE::mfma && !rfast;  // the row pass's first group has a row per lane: its twiddles differ per lane
+  constexpr bool on_mfma = LANE::template group_on_mfma<LOG_R, LOG_T, LAST>(g);
   constexpr int first_tw = on_mfma ? 4 : tw_needed(0) ? 0 : tw_needed(1) ? 1 : tw_needed(2) ? 2 : tw_needed(3) ? 3 : 4;
   fp2 tw_cur, tw_nxt;
   if constexpr (first_tw < 4) tw_cur = tw_load(first_tw);
@@ -305,7 +315,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     for (int h = 0; h < 4; ++h) {
       lds_put_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)), th.x[h]);
     }
-    if constexpr (tile_phase<LOG_R, LOG_T, LAST>(g) == tile_phase<LOG_R, LOG_T, LAST>(g + 1)) {
+    if constexpr (LANE::template phase<LOG_R, LOG_T, LAST>(g) == LANE::template phase<LOG_R, LOG_T, LAST>(g + 1)) {
       // the next group's elements were written by lanes of this wave: order the wave's own LDS traffic, nothing more
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -350,12 +360,12 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& 
   // once, or two, cost a wave per SIMD (106 / 102 VGPRs) and measured slower on single vectors and on 2^24.
   fp itw[4];
   auto itw_load = [&](int h) {
-    const uint32_t i = tile_ibase<LOG_R, LOG_T, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
+    const uint32_t i = LANE::template ibase<LOG_R, LOG_T, LAST, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
     const uint32_t k = __brev(i) >> (32 - LOG_R);
     return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
   };
   auto itw_request = [&]() {
-    if (!LAST && a.tw2 && !LANE::mfma) {  // (a matrix-core group leaves no registers for it)
+    if (!LAST && a.tw2 && LANE::itw_prefetch) {  // (matrix-core last groups leave no registers for it)
       itw[0] = itw_load(0);
     }
   };
@@ -402,7 +412,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& 
       if (a.scale) v = fp_mul(v, fp_load(a.scale));
       fp_store(a.dst + th.obase + ((uint64_t)k << a.log_P), v);
     } else {
-      if (LANE::mfma && a.tw2 && h == 0) itw[0] = itw_load(0);
+      if (!LANE::itw_prefetch && a.tw2 && h == 0) itw[0] = itw_load(0);
       if (a.tw2 && h + 1 < 4) itw[h + 1] = itw_load(h + 1);
       const fp tw = a.tw2 ? itw[h] : tw_lookup(a, th.j2 * k);
       fp v = fp_mul(th.x[h], tw);
@@ -415,6 +425,56 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& 
 template <int LOG_R, int LOG_T, bool LAST>
 __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) ntt_pass_kernel(NttPassArgs a) {
   ntt_pass_body<LOG_R, LOG_T, LAST>(a, ValuLane{});
+}
+
+// ---- launching a tile pass (any kernel built on ntt_pass_body) --------------------------------------------------------------
+// Tiles narrower than 128 bytes (T < 4: the big-radix passes) share their cache lines with the neighbouring tile; workgroups
+// are dealt to the 8 XCDs round-robin, so neighbours would sit behind different L2s and every line would be fetched (or
+// written back partially) twice.  Default (1): such launches map adjacent tiles to the same XCD (measured on the T = 1
+// variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ: 0 = never, 2 = every tile pass (measured level for T >= 4),
+// 3 = as 1 plus the sharer-fastest order below.
+inline int shk_xcd_swizzle() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_XCD_SWZ");
+    v = e ? atoi(e) : 1;
+    if (v < 0 || v > 3) v = 0;
+  }
+  return v;
+}
+
+// attr_done: one bit per device ordinal, per kernel instantiation (contexts on several devices, and on several host threads,
+// share the launcher)
+inline hipError_t shk_launch_tile_kernel(void (*k)(NttPassArgs), std::atomic<uint64_t>& attr_done, int log_t, unsigned threads,
+                                         size_t lds_bytes, bool last, const NttPassArgs& a, hipStream_t st) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    attr_done.fetch_or(bit, std::memory_order_release);
+  }
+  const uint64_t tiles = (a.total + ((1ull << log_t) - 1)) >> log_t;
+  if (tiles == 0) return hipSuccess;
+  if (tiles > 0x7ffffff0ull) return hipErrorInvalidValue;
+  NttPassArgs b = a;
+  uint64_t grid = tiles;
+  // column passes whose twiddle rows (tw2) are shared by several vectors / prefix blocks: sharer-fastest order, XCD-local.
+  // Opt-in only (STARKHIP_XCD_SWZ=3): it removes the per-vector re-fetch of the rows (2 * FETCH_SIZE of the 2^20 x 8 column
+  // pass 540 -> 325 MB) but measured 3-8 % SLOWER -- the sharers sit 2^k bytes apart, so the concurrently running tiles
+  // all map to the same memory channels.
+  const uint64_t sharers = last ? 0 : (a.total >> a.log_S);
+  const bool share = !last && a.tw2 && sharers >= 2 && sharers <= 0xffffffffull && a.log_S >= (uint32_t)log_t + 2 &&
+                     tiles <= 0xffffffffull && shk_xcd_swizzle() == 3;
+  if (shk_xcd_swizzle() && (shk_xcd_swizzle() == 2 || log_t < 2 || share) && tiles >= 64) {
+    b.xcd_per = (uint32_t)((tiles + 7) / 8);
+    b.sharers = share ? (uint32_t)sharers : 0;
+    grid = 8ull * b.xcd_per;
+  }
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, b);
+  return hipGetLastError();
 }
 
 // n <= 2: the reference's naive base case (_simple_ft, fft.py:287-300) is the whole transform.

@@ -331,7 +331,14 @@ hipError_t launch_ctile(const NttPassArgs& a, hipStream_t st) {
 // kernel above.  The row pass's first group (a row per lane) and the sparse first group of the low-degree extension stay
 // on the VALU butterflies.
 struct MfmaLane {
-  static constexpr bool mfma = true;
+  static constexpr bool itw_prefetch = false;  // no registers to spare across the last group
+  // every group but the row pass's first, whose lanes run along a row (a twiddle per lane)
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr bool group_on_mfma(int g) { return !(LAST && g == 0); }
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr int phase(int g) { return tile_phase<LOG_R, LOG_T, LAST>(g); }
+  template <int LOG_R, int LOG_T, bool LAST, int g>
+  static __device__ __forceinline__ uint32_t ibase(uint32_t tid) { return tile_ibase<LOG_R, LOG_T, g>(tid); }
   shk_v16i offs;
   uint32_t lane16, mlo, mhi;
 #ifdef SHK_STAMPS
@@ -377,10 +384,7 @@ struct MfmaLane {
   }
 };
 
-template <int LOG_R, bool LAST>
-__global__ void __launch_bounds__(8 << LOG_R) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_ltile_kernel(NttPassArgs a) {
-  static_assert(LOG_R >= 5 && LOG_R <= 7, "unsupported radix");
-  MfmaLane ln;
+__device__ __forceinline__ void lane_setup(MfmaLane& ln, const NttPassArgs& a) {
   const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
   for (int r = 0; r < 16; ++r) ln.offs[r] = (lane >> 5) ? SHK_OFFS[1][r] : SHK_OFFS[0][r];
@@ -390,7 +394,100 @@ __global__ void __launch_bounds__(8 << LOG_R) __attribute__((amdgpu_waves_per_eu
 #ifdef SHK_STAMPS
   ln.debug = a.debug;
 #endif
+}
+
+template <int LOG_R, bool LAST>
+__global__ void __launch_bounds__(8 << LOG_R) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_ltile_kernel(NttPassArgs a) {
+  static_assert(LOG_R >= 5 && LOG_R <= 7, "unsupported radix");
+  MfmaLane ln;
+  lane_setup(ln, a);
   ntt_pass_body<LOG_R, 5, LAST>(a, ln);
+}
+
+// ---- the VALU tile pass with its shared-twiddle groups on the matrix cores ---------------------------------------------------
+// The tile of ntt_kernels.cuh as it is (R x T elements, any radix, the same plans and the same HBM traffic as the VALU
+// passes).  The twiddle of a butterfly of level q depends on the low q bits of the row index only, so in the LATER groups of a
+// tile transform -- group g, level bits (beta, beta + 1), beta = LOG_R - 2 (g + 1) -- the 32 lanes of a half-wave share
+// their twiddles as soon as the low beta bits of their row indices agree: take those bits from the wave number and lane
+// bit 5, and let the lanes run over the columns and the HIGH row bits.  That mapping exists when beta <= 1 + log2(waves per
+// workgroup): the middle groups of the big radices (groups 2 and 3 of a 2^10-row tile of 2048 elements).  Those groups run the
+// generated blocks (mfma_group.inc); the first groups (a twiddle per lane) and the last one (twiddles 1 and w^(R/4)) keep the
+// VALU butterflies and their wave-local mapping; an exchange into or out of a matrix-core group crosses waves (a barrier).
+struct HybridLane : MfmaLane {
+  static constexpr bool itw_prefetch = true;  // the last group is a VALU group
+  // groups with the shared-twiddle mapping
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr bool shared(int g) {
+    const int beta = LOG_R - 2 * (g + 1), log_w = LOG_R + LOG_T - 8;
+    if ((LAST && g == 0) || LOG_T > 5 || log_w < 0) return false;
+    return beta > 0 && beta <= 1 + log_w;
+  }
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr bool group_on_mfma(int g) { return shared<LOG_R, LOG_T, LAST>(g); }
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr int phase(int g) {
+    return shared<LOG_R, LOG_T, LAST>(g) ? 100 + g : tile_phase<LOG_R, LOG_T, LAST>(g);
+  }
+  template <int LOG_R, int LOG_T, bool LAST, int g>
+  static __device__ __forceinline__ uint32_t ibase(uint32_t tid) {
+    if constexpr (!shared<LOG_R, LOG_T, LAST>(g)) {
+      return tile_ibase<LOG_R, LOG_T, g>(tid);
+    } else {
+      constexpr int beta = LOG_R - 2 * (g + 1);
+      const uint32_t lane = tid & 63u, wave = tid >> 6;
+      const uint32_t lane_i = (lane & 31u) >> LOG_T;   // 5 - LOG_T row bits run over the lanes of a half-wave
+      const uint32_t u = (lane >> 5) | (wave << 1);    // 1 + log2(waves) bits: the low beta row bits, the rest goes on top
+      const uint32_t hi = lane_i | ((u >> beta) << (5 - LOG_T));
+      return (u & ((1u << beta) - 1u)) | (hi << (beta + 2));
+    }
+  }
+};
+// experiment (STARKHIP_HYBRID_MATH=valu): the hybrid's mapping and barriers with every butterfly on the VALUs -- what the
+// shared-twiddle mapping costs by itself
+struct HybridMapOnlyLane : HybridLane {
+  template <int LOG_R, int LOG_T, bool LAST>
+  static constexpr bool group_on_mfma(int) { return false; }
+};
+
+template <int LOG_R, int LOG_T, bool LAST, class LANE>
+__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2)) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_htile_kernel(NttPassArgs a) {
+  LANE ln;
+  lane_setup(ln, a);
+  ntt_pass_body<LOG_R, LOG_T, LAST>(a, ln);
+}
+
+bool hybrid_math_on_valu() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_HYBRID_MATH");
+    v = (e && !strcmp(e, "valu")) ? 1 : 0;
+  }
+  return v == 1;
+}
+
+template <int LOG_R, bool LAST>
+hipError_t launch_htile(const NttPassArgs& a, hipStream_t st) {
+  constexpr int TILE_LOG = 11;  // 2048 elements, 512 threads: 64 KiB of LDS, two workgroups per CU, four waves per SIMD
+  constexpr int LOG_T = TILE_LOG - LOG_R;
+  static std::atomic<uint64_t> attr_done{0}, attr_done_v{0};
+  if (hybrid_math_on_valu())
+    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridMapOnlyLane>, attr_done_v, LOG_T, 1u << (TILE_LOG - 2),
+                                  (size_t)32 << TILE_LOG, LAST, a, st);
+  return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridLane>, attr_done, LOG_T, 1u << (TILE_LOG - 2),
+                                (size_t)32 << TILE_LOG, LAST, a, st);
+}
+
+template <bool LAST>
+hipError_t dispatch_htile(int log_R, const NttPassArgs& a, hipStream_t st) {
+  switch (log_R) {
+    case 6: return launch_htile<6, LAST>(a, st);
+    case 7: return launch_htile<7, LAST>(a, st);
+    case 8: return launch_htile<8, LAST>(a, st);
+    case 9: return launch_htile<9, LAST>(a, st);
+    case 10: return launch_htile<10, LAST>(a, st);
+    case 11: return launch_htile<11, LAST>(a, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <int LOG_R, bool LAST>
@@ -439,6 +536,7 @@ hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
 
 bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a) {
   if (a.mfma_kind == 2) return a.mats && log_R >= 5 && log_R <= 7 && (last || a.log_S >= 5);
+  if (a.mfma_kind == 3) return a.mats && log_R >= 6 && log_R <= 11 && (last || a.log_S >= (uint32_t)(11 - log_R));
   if (log_R < 5 || log_R > 8 || !a.mats) return false;
   if (!last && (a.log_S < 5 || !a.tw2)) return false;  // a tile's 32 columns must be adjacent
   return true;
@@ -446,5 +544,6 @@ bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a) {
 
 hipError_t shk_launch_ntt_pass_mfma(int log_R, bool last, const NttPassArgs& a, hipStream_t st) {
   if (a.mfma_kind == 2) return last ? dispatch_ltile<true>(log_R, a, st) : dispatch_ltile<false>(log_R, a, st);
+  if (a.mfma_kind == 3) return last ? dispatch_htile<true>(log_R, a, st) : dispatch_htile<false>(log_R, a, st);
   return last ? dispatch<true>(log_R, a, st) : dispatch<false>(log_R, a, st);
 }

@@ -1068,10 +1068,11 @@ def test_bench_two_ranks_share_this_gpu(sa, args):
         assert line["scaling"] == "strong" and line["unit"] == "proofs/s"
 
 
-@pytest.mark.parametrize("path", ["mfma", "mfma_lds"])
+@pytest.mark.parametrize("path", ["mfma", "mfma_lds", "hybrid"])
 def test_mfma_tile_passes_parity(sa, tmp_path, path):
     """The matrix-core tile passes (csrc/ntt_mfma.hip; the default is the integer-VALU passes) -- STARKHIP_NTT_PATH=mfma: the
-    tile in registers; mfma_lds: the LDS-resident 32-column tile with generated register groups: the NTT golden vectors, every
+    tile in registers; mfma_lds: the LDS-resident 32-column tile with generated register groups; hybrid: the VALU tile with its
+    shared-twiddle groups on the matrix cores: the NTT golden vectors, every
     size against the oracle, the 2^22 digest and a FRI + STARK proof, in a child process."""
     import subprocess, sys
     from conftest import ROOT
