@@ -465,9 +465,19 @@ bool hybrid_math_on_valu() {
   return v == 1;
 }
 
-template <int LOG_R, bool LAST>
-hipError_t launch_htile(const NttPassArgs& a, hipStream_t st) {
-  constexpr int TILE_LOG = 11;  // 2048 elements, 512 threads: 64 KiB of LDS, two workgroups per CU, four waves per SIMD
+// STARKHIP_HYBRID_TILE_LOG = 10: 1024-element tiles (256 threads, 32 KiB: four workgroups per CU, one wave of each per SIMD) for the
+// radices that fit; default 11: 2048 elements, 512 threads, 64 KiB of LDS, two workgroups per CU
+int hybrid_tile_log() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_HYBRID_TILE_LOG");
+    v = (e && atoi(e) == 10) ? 10 : 11;
+  }
+  return v;
+}
+
+template <int LOG_R, bool LAST, int TILE_LOG>
+hipError_t launch_htile_sized(const NttPassArgs& a, hipStream_t st) {
   constexpr int LOG_T = TILE_LOG - LOG_R;
   static std::atomic<uint64_t> attr_done{0}, attr_done_v{0};
   if (hybrid_math_on_valu())
@@ -477,9 +487,19 @@ hipError_t launch_htile(const NttPassArgs& a, hipStream_t st) {
                                 (size_t)32 << TILE_LOG, LAST, a, st);
 }
 
+template <int LOG_R, bool LAST>
+hipError_t launch_htile(const NttPassArgs& a, hipStream_t st) {
+  if constexpr (LOG_R <= 10 && LOG_R >= 5) {
+    if (hybrid_tile_log() == 10 && (LAST || a.log_S >= (uint32_t)(10 - LOG_R))) return launch_htile_sized<LOG_R, LAST, 10>(a, st);
+  }
+  if constexpr (LOG_R >= 6) return launch_htile_sized<LOG_R, LAST, 11>(a, st);
+  return hipErrorInvalidValue;
+}
+
 template <bool LAST>
 hipError_t dispatch_htile(int log_R, const NttPassArgs& a, hipStream_t st) {
   switch (log_R) {
+    case 5: return launch_htile<5, LAST>(a, st);
     case 6: return launch_htile<6, LAST>(a, st);
     case 7: return launch_htile<7, LAST>(a, st);
     case 8: return launch_htile<8, LAST>(a, st);
@@ -536,7 +556,11 @@ hipError_t dispatch(int log_R, const NttPassArgs& a, hipStream_t st) {
 
 bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a) {
   if (a.mfma_kind == 2) return a.mats && log_R >= 5 && log_R <= 7 && (last || a.log_S >= 5);
-  if (a.mfma_kind == 3) return a.mats && log_R >= 6 && log_R <= 11 && (last || a.log_S >= (uint32_t)(11 - log_R));
+  if (a.mfma_kind == 3) {
+    if (!a.mats) return false;
+    if (hybrid_tile_log() == 10 && log_R >= 5 && log_R <= 10 && (last || a.log_S >= (uint32_t)(10 - log_R))) return true;
+    return log_R >= 6 && log_R <= 11 && (last || a.log_S >= (uint32_t)(11 - log_R));
+  }
   if (log_R < 5 || log_R > 8 || !a.mats) return false;
   if (!last && (a.log_S < 5 || !a.tw2)) return false;  // a tile's 32 columns must be adjacent
   return true;
