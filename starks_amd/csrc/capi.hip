@@ -636,6 +636,8 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
     {
       const char* e = getenv("STARKHIP_STAMP_PASS");
       a.debug = (size_t)(e ? atoi(e) : (int)m - 1) == d;
+      const char* sb = getenv("STARKHIP_STAMP_BASE");  // LDS-tile / hybrid kernels: first recorded workgroup (a multiple of 1024)
+      if (a.debug && sb) a.debug = 1u + (uint32_t)atoi(sb) / 1024u;
     }
 #endif
     if (shk_ntt_mfma_supports(r, last, a))

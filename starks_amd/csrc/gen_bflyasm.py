@@ -902,6 +902,7 @@ def emit_inc(path):
 # Four elements per thread (x[h] pinned to v[96 + 8 h ..]), two DIF levels = up to four butterflies.  The twiddle of a butterfly
 # is the same for the 32 lanes of a half-wave (they are the 32 columns of one row); the kernel passes the byte offsets of the two
 # TwMat images (lanes 0..31 / 32..63) of every MFMA butterfly as scalar operands o<k>lo / o<k>hi.
+GROUP_PRIO = int(os.environ.get("SHK_GROUP_PRIO", "0"))  # experiment: s_setprio around a block (measured: no effect)
 GROUP_PATTERNS = {
     # name: [(m0, m1, kind)], kind "M" = MFMA butterfly with a table twiddle, "A" = twiddle 1 (add / sub)
     "MMMM": [(0, 2, "M"), (1, 3, "M"), (0, 1, "M"), (2, 3, "M")],   # both levels general
@@ -928,6 +929,8 @@ def build_group(pattern):
     """the scheduled block of one register group; returns (sched, butterfly list [(m0, m1, slot or None)])"""
     Label.count = 0
     sched = Sched()
+    if GROUP_PRIO:
+        sched.emit(I("s_setprio %d" % GROUP_PRIO, "salu"))   # a latency-bound block between VALU-dense waves: issue first
     for ins in prologue(2, 0):   # constants + base = the TwMat table
         sched.emit(ins)
     bf = []
@@ -970,6 +973,8 @@ def build_group(pattern):
         prev_mf = j
     sched.run(streams)
     sched.emit(I("s_nop 1", "nop"))
+    if GROUP_PRIO:
+        sched.emit(I("s_setprio 0", "salu"))
     return sched, bf
 
 

@@ -344,7 +344,9 @@ struct MfmaLane {
 #ifdef SHK_STAMPS
   uint32_t debug;
   __device__ __forceinline__ void stamp(int k) const {
-    if (debug && threadIdx.x == 0 && blockIdx.x < 1024) g_stamps[k][blockIdx.x] = __builtin_amdgcn_s_memtime();
+    // debug = 1 + first recorded workgroup / 1024: workgroups [1024 (debug - 1), 1024 debug) record (STARKHIP_STAMP_BASE)
+    const uint32_t b = blockIdx.x - 1024u * (debug - 1u);
+    if (debug && threadIdx.x == 0 && b < 1024u) g_stamps[k][b] = __builtin_amdgcn_s_memtime();
   }
 #else
   __device__ __forceinline__ void stamp(int) const {}
@@ -449,6 +451,30 @@ struct HybridMapOnlyLane : HybridLane {
   static constexpr bool group_on_mfma(int) { return false; }
 };
 
+// timing experiment only (STARKHIP_HYBRID_MATH=skip, WRONG RESULTS): the shared groups exchange their elements and do no
+// arithmetic at all -- the ceiling of what any faster butterfly in those groups could return
+struct HybridSkipLane : HybridLane {
+  template <int LOG_R, int g>
+  __device__ __forceinline__ void butterflies(TileThread&) const {}
+};
+// timing experiment only (STARKHIP_HYBRID_MATH=frag0, WRONG RESULTS): every butterfly multiplies by the table's first entry, so the
+// operand-image loads always hit the L1 -- what the latency of those loads costs
+struct HybridFrag0Lane : HybridLane {
+  template <int LOG_R, int g>
+  __device__ __forceinline__ void butterflies(TileThread& th) const {
+    shk_x8 xv[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xv[h][i] = th.x[h].v[i];
+    shk_group_asm_MMMM(xv, offs, lane16, mlo, mhi, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) th.x[h].v[i] = xv[h][i];
+  }
+};
+
 template <int LOG_R, int LOG_T, bool LAST, class LANE>
 __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2)) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_htile_kernel(NttPassArgs a) {
   LANE ln;
@@ -460,10 +486,12 @@ bool hybrid_math_on_valu() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_HYBRID_MATH");
-    v = (e && !strcmp(e, "valu")) ? 1 : 0;
+    v = (e && !strcmp(e, "valu")) ? 1 : (e && !strcmp(e, "skip")) ? 2 : 0;
   }
   return v == 1;
 }
+bool hybrid_math_frag0() { return getenv("STARKHIP_HYBRID_MATH") && !strcmp(getenv("STARKHIP_HYBRID_MATH"), "frag0"); }
+bool hybrid_math_skipped() { return hybrid_math_on_valu(), getenv("STARKHIP_HYBRID_MATH") && !strcmp(getenv("STARKHIP_HYBRID_MATH"), "skip"); }
 
 // STARKHIP_HYBRID_TILE_LOG = 10: 1024-element tiles (256 threads, 32 KiB: four workgroups per CU, one wave of each per SIMD) for the
 // radices that fit; default 11: 2048 elements, 512 threads, 64 KiB of LDS, two workgroups per CU
@@ -479,7 +507,13 @@ int hybrid_tile_log() {
 template <int LOG_R, bool LAST, int TILE_LOG>
 hipError_t launch_htile_sized(const NttPassArgs& a, hipStream_t st) {
   constexpr int LOG_T = TILE_LOG - LOG_R;
-  static std::atomic<uint64_t> attr_done{0}, attr_done_v{0};
+  static std::atomic<uint64_t> attr_done{0}, attr_done_v{0}, attr_done_s{0}, attr_done_f{0};
+  if (hybrid_math_frag0())
+    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridFrag0Lane>, attr_done_f, LOG_T, 1u << (TILE_LOG - 2),
+                                  (size_t)32 << TILE_LOG, LAST, a, st);
+  if (hybrid_math_skipped())
+    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridSkipLane>, attr_done_s, LOG_T, 1u << (TILE_LOG - 2),
+                                  (size_t)32 << TILE_LOG, LAST, a, st);
   if (hybrid_math_on_valu())
     return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridMapOnlyLane>, attr_done_v, LOG_T, 1u << (TILE_LOG - 2),
                                   (size_t)32 << TILE_LOG, LAST, a, st);
