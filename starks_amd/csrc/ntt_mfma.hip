@@ -451,6 +451,7 @@ struct HybridMapOnlyLane : HybridLane {
   static constexpr bool group_on_mfma(int) { return false; }
 };
 
+#ifdef SHK_STAMPS  // the diagnostic library only (make stamps): these two variants give WRONG RESULTS by design
 // timing experiment only (STARKHIP_HYBRID_MATH=skip, WRONG RESULTS): the shared groups exchange their elements and do no
 // arithmetic at all -- the ceiling of what any faster butterfly in those groups could return
 struct HybridSkipLane : HybridLane {
@@ -474,6 +475,7 @@ struct HybridFrag0Lane : HybridLane {
       for (int i = 0; i < 8; ++i) th.x[h].v[i] = xv[h][i];
   }
 };
+#endif
 
 template <int LOG_R, int LOG_T, bool LAST, class LANE>
 __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2)) __attribute__((amdgpu_waves_per_eu(4, 4))) ntt_htile_kernel(NttPassArgs a) {
@@ -482,16 +484,20 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2)) __attribute__((amdgp
   ntt_pass_body<LOG_R, LOG_T, LAST>(a, ln);
 }
 
-bool hybrid_math_on_valu() {
+// STARKHIP_HYBRID_MATH: 0 = the blocks (default), 1 = "valu"; the diagnostic library also knows 2 = "skip", 3 = "frag0"
+int hybrid_math() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("STARKHIP_HYBRID_MATH");
-    v = (e && !strcmp(e, "valu")) ? 1 : (e && !strcmp(e, "skip")) ? 2 : 0;
+    int m = (e && !strcmp(e, "valu")) ? 1 : 0;
+#ifdef SHK_STAMPS
+    if (e && !strcmp(e, "skip")) m = 2;
+    if (e && !strcmp(e, "frag0")) m = 3;
+#endif
+    v = m;
   }
-  return v == 1;
+  return v;
 }
-bool hybrid_math_frag0() { return getenv("STARKHIP_HYBRID_MATH") && !strcmp(getenv("STARKHIP_HYBRID_MATH"), "frag0"); }
-bool hybrid_math_skipped() { return hybrid_math_on_valu(), getenv("STARKHIP_HYBRID_MATH") && !strcmp(getenv("STARKHIP_HYBRID_MATH"), "skip"); }
 
 // STARKHIP_HYBRID_TILE_LOG = 10: 1024-element tiles (256 threads, 32 KiB: four workgroups per CU, one wave of each per SIMD) for the
 // radices that fit; default 11: 2048 elements, 512 threads, 64 KiB of LDS, two workgroups per CU
@@ -507,18 +513,19 @@ int hybrid_tile_log() {
 template <int LOG_R, bool LAST, int TILE_LOG>
 hipError_t launch_htile_sized(const NttPassArgs& a, hipStream_t st) {
   constexpr int LOG_T = TILE_LOG - LOG_R;
-  static std::atomic<uint64_t> attr_done{0}, attr_done_v{0}, attr_done_s{0}, attr_done_f{0};
-  if (hybrid_math_frag0())
-    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridFrag0Lane>, attr_done_f, LOG_T, 1u << (TILE_LOG - 2),
-                                  (size_t)32 << TILE_LOG, LAST, a, st);
-  if (hybrid_math_skipped())
-    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridSkipLane>, attr_done_s, LOG_T, 1u << (TILE_LOG - 2),
-                                  (size_t)32 << TILE_LOG, LAST, a, st);
-  if (hybrid_math_on_valu())
-    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridMapOnlyLane>, attr_done_v, LOG_T, 1u << (TILE_LOG - 2),
-                                  (size_t)32 << TILE_LOG, LAST, a, st);
-  return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridLane>, attr_done, LOG_T, 1u << (TILE_LOG - 2),
-                                (size_t)32 << TILE_LOG, LAST, a, st);
+  constexpr unsigned THREADS = 1u << (TILE_LOG - 2);
+  constexpr size_t LDS = (size_t)32 << TILE_LOG;
+  static std::atomic<uint64_t> attr_done{0}, attr_done_v{0};
+#ifdef SHK_STAMPS
+  static std::atomic<uint64_t> attr_done_s{0}, attr_done_f{0};
+  if (hybrid_math() == 3)
+    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridFrag0Lane>, attr_done_f, LOG_T, THREADS, LDS, LAST, a, st);
+  if (hybrid_math() == 2)
+    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridSkipLane>, attr_done_s, LOG_T, THREADS, LDS, LAST, a, st);
+#endif
+  if (hybrid_math() == 1)
+    return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridMapOnlyLane>, attr_done_v, LOG_T, THREADS, LDS, LAST, a, st);
+  return shk_launch_tile_kernel(ntt_htile_kernel<LOG_R, LOG_T, LAST, HybridLane>, attr_done, LOG_T, THREADS, LDS, LAST, a, st);
 }
 
 template <int LOG_R, bool LAST>
