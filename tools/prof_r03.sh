@@ -1,6 +1,7 @@
 # Round-3 evidence, all from ONE box and ONE session: the bench line, then the same `bench.py` command under rocprofv3 --
 # kernel stats, FETCH_SIZE / WRITE_SIZE (separate passes), VALU counters -- for the headline (one 2^24-point vector) and for
 # 8 x 2^20; the FRI commit of a 2^20-step trace, the 2^24-leaf Merkle commit and config 5 under the kernel trace.
+# (send this script's own output to a file that does NOT match gpurun_out/r3p_*: the next line removes those)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/r3p_*
 python3 bench.py > gpurun_out/r3p_bench.json 2> gpurun_out/r3p_bench.err || { tail -5 gpurun_out/r3p_bench.err; exit 1; }
