@@ -292,8 +292,9 @@ int tw2_max_log() {
   if (v < 0) {
     const char* e = getenv("STARKHIP_TW2_MAX_LOG");
     // measured: +5..9 % up to 2^20-entry tables; with the twiddle loads requested ahead of use a 2^23-entry table (256 MiB,
-    // the first pass of the 2^23-point transform of a 2^20-step FRI commit) gains 4 %, a 2^24-entry one (512 MiB) 1-2 %
-    v = e ? atoi(e) : 23;
+    // the first pass of the 2^23-point transform of a 2^20-step FRI commit) gains 4 %, a 2^24-entry one (512 MiB) 1.3-2.4 %
+    // (round 3, three rounds in one session) -- taken since the plan cache has a byte budget; 2^25 entries measured 0.7 % behind
+    v = e ? atoi(e) : 24;
     if (v < 0) v = 0;
     if (v > 28) v = 28;
   }
@@ -548,7 +549,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         fp* tw2 = nullptr;
         const int log_S = pl->log_n - log_P - r;
         if (rc == SH_OK && r + log_S <= tw2_max_log()) {
-          // a failed allocation of the row table (up to 256 MiB) is not fatal: the pass keeps the power-table lookup
+          // a failed allocation of the row table (up to 512 MiB) is not fatal: the pass keeps the power-table lookup
           void* dv = nullptr;
           if (plan_alloc(c, pl, sizeof(fp) << (r + log_S), &dv) == SH_OK) {
             tw2 = reinterpret_cast<fp*>(dv);
