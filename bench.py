@@ -17,7 +17,8 @@ columns per launch sequence), `fri_commit_ms_2^20_trace` / `fri_commit_ms_2^14_t
 
 Workload `c5` (BASELINE configs[4]): `--units` (512) independent 2^16-step MiMC STARK proofs (STARK.mk_proof,
 stark.py:233-279; unit j = test_stark.py:265-293 started from 3 + j), sharded over the ranks by proof index
-(starks_amd/batch.py:shard), `--chunk` (128) proofs per batched launch; a step = the whole batch once; `value` = proofs/s; strong
+(starks_amd/batch.py:shard), `--chunk` (128) proofs per batched launch, the launches dealt in turn to `--c5-streams` (2) library
+contexts; a step = the whole batch once; `value` = proofs/s; strong
 scaling; the only exchange is one all_gather of the 64-byte proof headers (m_root | l_root) per step (RCCL).  Every run of
 the default workload also runs three such steps after its timed region and reports it under `c5` / `c5_proofs_per_s`, so
 that the driver's N = 1, 2, 4, 8 runs record the proofs/s curve too.
@@ -93,7 +94,7 @@ class ProofShard:
     """This rank's units of the many-proof workload, resident in HBM: the witnesses (generated on the device,
     untimed; the prover leaves them intact) and the flat proofs of the whole shard."""
 
-    def __init__(self, dev, units, steps, ext=8, chunk=128):
+    def __init__(self, dev, units, steps, ext=8, chunk=128, streams=1):
         from starks_amd import stark
         from starks_amd.modp import IntegersModP
         from starks_amd.multivariate_polynomial import generate_Xi_s
@@ -112,12 +113,21 @@ class ProofShard:
             assert self.units == list(range(self.units[0], self.units[0] + len(self.units)))
             dev.ck(L.sh_dev_fill_mimc_units(ctx, self.d_wit, self.d_inp, steps, self.units[0], len(self.units), 42), "fill units")
         dev.sync()
+        # `streams` library contexts on this GPU (each one stream and its own workspaces): successive batched launches go to them
+        # in turn, so that the latency-bound tail of one launch sequence (the small FRI rounds) runs beside the wide kernels of
+        # the next (include/starkhip.h: contexts are independent; device buffers belong to the device, not to a context)
+        self.ctxs = [ctx]
+        for _ in range(1, max(1, streams)):
+            other = ctypes.c_void_p()
+            dev.ck(L.sh_ctx_create(dev._lib.default_device(), ctypes.byref(other)), "sh_ctx_create")
+            self.ctxs.append(other)
 
     def prove_all(self):
         """One step: every unit of the shard, `chunk` per launch sequence; asynchronous on the library stream."""
-        dev, L, ctx = self.dev, self.dev.L, self.dev.ctx
-        for c in range(0, len(self.units), self.chunk):
+        dev, L = self.dev, self.dev.L
+        for j, c in enumerate(range(0, len(self.units), self.chunk)):
             k = min(self.chunk, len(self.units) - c)
+            ctx = self.ctxs[j % len(self.ctxs)]
             dev.ck(L.sh_dev_stark_prove(ctx, ctypes.c_void_p(self.d_wit.value + self.wbytes * c),
                                         ctypes.c_void_p(self.d_inp.value + 64 * c), self.steps, self.ext, 2,
                                         self.coefs, self.exps, self.counts, 80, k,
@@ -126,9 +136,10 @@ class ProofShard:
     def headers(self):
         """m_root | l_root of every proof of the shard (64 B each); synchronises; raises on an invalid witness."""
         k = len(self.units)
-        rc = self.dev.L.sh_stark_status(self.dev.ctx)
-        if rc != 0:
-            self.dev.ck(rc, "stark status")
+        for ctx in self.ctxs:  # every context's stream drained, every context's witness flags read
+            rc = self.dev.L.sh_stark_status(ctx)
+            if rc != 0:
+                self.dev.ck(rc, "stark status")
         out = ctypes.create_string_buffer(64 * max(k, 1))
         if k:
             self.dev.ck(self.dev.L.sh_dev_download_2d(self.dev.ctx, self.d_proofs, self.plen, out, 64, k), "headers")
@@ -142,6 +153,9 @@ class ProofShard:
     def close(self):
         for p in (self.d_wit, self.d_inp, self.d_proofs):
             self.dev.free(p)
+        for other in self.ctxs[1:]:
+            self.dev.L.sh_ctx_destroy(other)
+        self.ctxs = self.ctxs[:1]
 
 
 def gather_headers(local, total, rank, world, dist, tdev, force=False):
@@ -405,6 +419,8 @@ def main():
     ap.add_argument("--units", type=int, default=None, help="c5: proofs in the batch (512; 16 with --quick)")
     ap.add_argument("--logsteps", type=int, default=None, help="c5: log2 trace length (16; 10 with --quick)")
     ap.add_argument("--chunk", type=int, default=128, help="c5: proofs per batched launch")
+    ap.add_argument("--c5-streams", type=int, default=2, help="c5: library contexts (streams) the batched launches are dealt to "
+                    "in turn (measured: 2 is worth 1-1.5 %% over 1; 3 and 4 no more)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-c5", action="store_true", help="ntt: skip the many-proof leg")
     ap.add_argument("--no-single", action="store_true", help="ntt: skip the single-vector leg (profiling runs: keeps the "
@@ -487,7 +503,7 @@ def main():
         """K timed steps of the many-proof workload; returns the result dict (rank-independent fields agree on all ranks)."""
         steps = 1 << args.logsteps
         mine = shard(args.units, rank, world)
-        sh = ProofShard(dev, mine, steps, 8, args.chunk)
+        sh = ProofShard(dev, mine, steps, 8, args.chunk, args.c5_streams)
         heads = None
         for _ in range(warm_k):
             sh.prove_all()
