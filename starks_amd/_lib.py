@@ -14,6 +14,7 @@ MIMC_P = 2**256 - 2**32 * 351 + 1  # starks/utils.py:22
 
 _lib = None
 _ctx = None
+_ctx2 = None
 _lock = threading.Lock()
 
 
@@ -132,9 +133,27 @@ def ctx():
         return _ctx
 
 
-def close():
-    global _ctx
+def second_ctx():
+    """A second context on the same GPU (its own stream, workspaces and plan cache; include/starkhip.h: contexts are
+    independent), created on first use and kept for the life of the process: the many-proof driver pipelines two batches."""
+    global _ctx2
+    ctx()
     with _lock:
+        if _ctx2 is None:
+            h = ctypes.c_void_p()
+            rc = lib().sh_ctx_create(default_device(), ctypes.byref(h))
+            if rc != 0:
+                raise StarkHipError(rc, "sh_ctx_create", "second context")
+            _ctx2 = h
+        return _ctx2
+
+
+def close():
+    global _ctx, _ctx2
+    with _lock:
+        if _ctx2 is not None:
+            lib().sh_ctx_destroy(_ctx2)
+            _ctx2 = None
         if _ctx is not None:
             lib().sh_ctx_destroy(_ctx)
             _ctx = None

@@ -5,6 +5,7 @@ backend "nccl" = RCCL on ROCm, "gloo" in CPU tests), rank r proves the units `sh
 the only exchange is one all_gather of the 32-byte proof digests at the end -- no collective inside a proof.
 """
 import hashlib
+import os
 
 from ._lib import MIMC_P
 
@@ -99,33 +100,61 @@ def prove_stark_units_device(first_unit, count, steps, ext=8, chunk=32, keep=Non
     unit ids whose flat proofs are returned too.  -> (digests in unit order, {unit: flat proof}).
 
     This is what bench.py --workload c5 times; `StarkUnitProver` below exposes the pieces so that generation can stay untimed."""
-    pr = StarkUnitProver(steps, ext, chunk, constant)
+    # Two provers, the second on a library context (stream + workspaces) of its own: batch j is launched before batch j - 1 is
+    # downloaded and digested, so that the host side of one batch runs beside the device side of the next.  Downloads land in
+    # page-locked buffers (no staging copy) and are hashed in place, several proofs at a time (hashlib releases the GIL).
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _lib
+    provers = [StarkUnitProver(steps, ext, chunk, constant)]
+    if count > chunk:
+        provers.append(StarkUnitProver(steps, ext, chunk, constant, second_context=True))
+    bufs = [_lib.PinnedBuffer(pr.plen * chunk) for pr in provers]
+    pool = ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1))
     try:
         digs, kept = [], {}
-        for c in range(0, count, chunk):
+
+        def collect(which, first, k):
+            pr, plen = provers[which], provers[which].plen
+            mv = memoryview(pr.download_into(k, bufs[which]))
+            digs.extend(pool.map(lambda i: hashlib.sha256(mv[i * plen:(i + 1) * plen]).digest(), range(k)))
+            if keep:
+                for i in range(k):
+                    if first + i in keep:
+                        kept[first + i] = bytes(mv[i * plen:(i + 1) * plen])
+
+        pending = None
+        for j, c in enumerate(range(0, count, chunk)):
             k = min(chunk, count - c)
-            pr.generate(first_unit + c, k)
-            pr.prove(k)
-            flats = pr.download(k)
-            for i, flat in enumerate(flats):
-                digs.append(digest(flat))
-                if keep and first_unit + c + i in keep:
-                    kept[first_unit + c + i] = flat
+            which = j % len(provers)
+            provers[which].generate(first_unit + c, k)
+            provers[which].prove(k)
+            if pending is not None:
+                collect(*pending)
+            pending = (which, first_unit + c, k)
+        if pending is not None:
+            collect(*pending)
         return digs, kept
     finally:
-        pr.close()
+        pool.shutdown()
+        for b in bufs:
+            b.close()
+        for pr in provers:
+            pr.close()
 
 
 class StarkUnitProver(object):
     """Device buffers for `chunk` MiMC STARK units of `steps` steps: generate() fills witnesses and inputs on the device,
-    prove() launches sh_dev_stark_prove on them (asynchronous), status()/download() synchronise."""
+    prove() launches sh_dev_stark_prove on them (asynchronous), status()/download() synchronise.  second_context: the
+    process's second library context instead of the first (another stream: prove_stark_units_device pipelines two provers)."""
 
-    def __init__(self, steps, ext=8, chunk=32, constant=42):
+    def __init__(self, steps, ext=8, chunk=32, constant=42, second_context=False):
         import ctypes
         from . import _lib, stark
         from .modp import IntegersModP
         from .multivariate_polynomial import generate_Xi_s
         self._lib, self.L, self.ctx = _lib, _lib.lib(), _lib.ctx()
+        if second_context:  # the process's second stream on the same GPU (_lib.second_ctx)
+            self.ctx = _lib.second_ctx()
         self.steps, self.ext, self.chunk, self.constant = steps, ext, chunk, constant
         X1, X2 = generate_Xi_s(IntegersModP(MIMC_P), 2)
         self.coefs, self.exps, self.counts, self.degree = stark.pack_step_polys([X1, X1 + X2**3], 2)
@@ -150,6 +179,12 @@ class StarkUnitProver(object):
         if rc == -8:
             raise AssertionError("a witness of the batch is not a valid trace")
         self._lib.check(rc, "sh_stark_status")
+
+    def download_into(self, k, pinned):
+        """The k flat proofs into a page-locked buffer (_lib.PinnedBuffer of at least k * plen bytes); returns its ctypes view."""
+        self.status()
+        self._lib.check(self.L.sh_dev_download(self.ctx, self.dp, pinned.view, self.plen * k), "sh_dev_download")
+        return pinned.view
 
     def download(self, k):
         import ctypes
