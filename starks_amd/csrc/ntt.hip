@@ -25,8 +25,33 @@ int tile_log_choice() {
   return v;
 }
 
+// The FIRST column pass of a long transform (P = 1: the rows of a tile are n / R elements apart) gets 2048-element tiles once that
+// distance reaches 2 MiB (n / R >= 2^16): twice the columns per row (256-byte segments at radix 2^8) are worth + 3.6 % on a
+// 2^24-point transform and + 4 % on two of them (measured in alternation, profiles/r03_first_pass_tile_2p24.txt); below that
+// distance the 1024-element tiles of the other passes stay ahead (2^21: - 0.5 .. - 4 %, 2^22 / 2^23: +- 1 %), and so they do for
+// the radix-2^7 first pass of the four-pass plan of 2^25 points (16 columns per row: - 1.7 %): the rule is radix 2^8 only.
+// STARKHIP_TILE_LOG_FIRST = 10 | 11 | 12 forces a size for every first pass.
+int tile_log_first() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("STARKHIP_TILE_LOG_FIRST");
+    v = e ? atoi(e) : 0;
+    if (v != 10 && v != 11 && v != 12) v = 0;
+  }
+  return v;
+}
+
 template <int LOG_R, bool LAST>
 hipError_t launch(const NttPassArgs& a, hipStream_t st) {
+  if constexpr (!LAST) {
+    static const bool tile_forced = getenv("STARKHIP_TILE_LOG") != nullptr;  // an explicit tile size applies to every pass
+    if (a.log_S + LOG_R == a.log_n && !tile_forced) {
+      const int f = tile_log_first() ? tile_log_first() : ((LOG_R == 8 && a.log_S >= 16) ? 11 : 0);
+      if (f == 12) return launch_tile<LOG_R, LAST, 12>(a, st);
+      if (f == 11) return launch_tile<LOG_R, LAST, 11>(a, st);
+      if (f == 10) return launch_tile<LOG_R, LAST, 10>(a, st);
+    }
+  }
   if (tile_log_choice() == 10) return launch_tile<LOG_R, LAST, 10>(a, st);
   if (tile_log_choice() == 9) return launch_tile<LOG_R, LAST, 9>(a, st);
   return launch_tile<LOG_R, LAST, 11>(a, st);
