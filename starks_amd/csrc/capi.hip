@@ -633,6 +633,7 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
     }
     a.mats = use_mfma_path() ? pl->mats[d] : nullptr;
     a.mfma_kind = (uint32_t)mfma_kind();
+    a.pass_index = (uint32_t)d;
 #ifdef SHK_STAMPS
     {
       const char* e = getenv("STARKHIP_STAMP_PASS");

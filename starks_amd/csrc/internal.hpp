@@ -27,6 +27,7 @@ struct NttPassArgs {
   uint32_t debug;     // diagnostic (SHK_STAMPS) builds only: 1 = this pass records its phase stamps
   const fp* tw2;      // MFMA column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k); else null
   const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null
+  uint32_t pass_index; // 0 = the first pass of the transform (experiments: STARKHIP_TILE_LOGS picks a tile size per pass)
   uint32_t mfma_kind; // with mats: 1 = the register tile (R x 32 in registers), 2 = the LDS-resident R x 32 tile with MFMA groups
   uint32_t xcd_per;   // 0: tile = blockIdx.x.  Else workgroups are dealt to the 8 XCDs round-robin and tile = (blockIdx.x & 7) *
                       // xcd_per + (blockIdx.x >> 3): adjacent tiles run on the SAME XCD (they share 128-byte lines when T < 4)

@@ -41,8 +41,34 @@ int tile_log_first() {
   return v;
 }
 
+// experiments: STARKHIP_TILE_LOGS="11,10,10": elements per tile (log2) of pass 0, 1, 2, ... of every transform (0 = default rule)
+int tile_log_of_pass(uint32_t d) {
+  static int v[8] = {-1, 0, 0, 0, 0, 0, 0, 0};
+  if (v[0] < 0) {
+    int t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (const char* e = getenv("STARKHIP_TILE_LOGS")) {
+      int i = 0;
+      for (const char* p = e; *p && i < 8; ++i) {
+        char* end = nullptr;
+        const long x = strtol(p, &end, 10);
+        if (end == p) break;
+        t[i] = (x >= 9 && x <= 12) ? (int)x : 0;
+        p = (*end == ',') ? end + 1 : end;
+      }
+    }
+    for (int i = 7; i >= 0; --i) v[i] = t[i];
+  }
+  return d < 8 ? v[d] : 0;
+}
+
 template <int LOG_R, bool LAST>
 hipError_t launch(const NttPassArgs& a, hipStream_t st) {
+  if (const int f = tile_log_of_pass(a.pass_index)) {
+    if (f == 12 && LOG_R >= 4) return launch_tile<LOG_R, LAST, 12>(a, st);
+    if (f == 11) return launch_tile<LOG_R, LAST, 11>(a, st);
+    if (f == 10) return launch_tile<LOG_R, LAST, 10>(a, st);
+    if (f == 9) return launch_tile<LOG_R, LAST, 9>(a, st);
+  }
   if constexpr (!LAST) {
     static const bool tile_forced = getenv("STARKHIP_TILE_LOG") != nullptr;  // an explicit tile size applies to every pass
     if (a.log_S + LOG_R == a.log_n && !tile_forced) {
@@ -70,6 +96,13 @@ int big_tile_log_choice() {
 }
 template <int LOG_R, bool LAST>
 hipError_t launch_big(const NttPassArgs& a, hipStream_t st) {
+  if (const int f = tile_log_of_pass(a.pass_index)) {
+    if (f == 12) return launch_tile<LOG_R, LAST, 12>(a, st);
+    if (f == 11) return launch_tile<LOG_R, LAST, 11>(a, st);
+    if constexpr (LOG_R <= 10) {
+      if (f == 10) return launch_tile<LOG_R, LAST, 10>(a, st);
+    }
+  }
   if constexpr (LOG_R <= 10) {
     if (big_tile_log_choice() == 10) return launch_tile<LOG_R, LAST, 10>(a, st);
   }
