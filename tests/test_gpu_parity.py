@@ -1092,7 +1092,8 @@ def test_mfma_tile_passes_parity(sa, tmp_path, path):
     {"STARKHIP_NTT_RADICES": "11,9", "STARKHIP_TILE_LOG_BIG": "11"},  # radix 2^11: one column / one row per tile
     {"STARKHIP_NTT_RADICES": "6,6,4", "STARKHIP_TILE_LOG": "11"},     # 2^16 in three passes, 2048-element tiles
     {"STARKHIP_XCD_SWZ": "3"},                                        # column tiles in sharer-fastest order
-], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "sharer_order"])
+    {"STARKHIP_TILE_LOGS": "11,9,10", "STARKHIP_TW2_MAX_LOG": "20"},  # a tile size per pass; small row tables (lookup fallback)
+], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "sharer_order", "per_pass_tiles"])
 def test_alternate_ntt_plans_parity(sa, env):
     """Every decomposition the plan / tile knobs can select gives the same bytes: the NTT golden vectors (reference digests to
     2^20), every size against the oracle and the 2^22 / 2^24 digests, in a child process with the knobs set."""
