@@ -442,6 +442,26 @@ inline int shk_xcd_swizzle() {
   }
   return v;
 }
+// experiments: STARKHIP_XCD_SWZS="2,1,0": the mode of pass 0, 1, 2, ... (-1 / absent = STARKHIP_XCD_SWZ)
+inline int shk_xcd_swizzle_of_pass(uint32_t d) {
+  static int v[8] = {-2, -1, -1, -1, -1, -1, -1, -1};
+  if (v[0] == -2) {
+    int t[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    if (const char* e = getenv("STARKHIP_XCD_SWZS")) {
+      int i = 0;
+      for (const char* p = e; *p && i < 8; ++i) {
+        char* end = nullptr;
+        const long x = strtol(p, &end, 10);
+        if (end == p) break;
+        t[i] = (x >= 0 && x <= 3) ? (int)x : -1;
+        p = (*end == ',') ? end + 1 : end;
+      }
+    }
+    for (int i = 7; i >= 0; --i) v[i] = t[i];
+  }
+  const int m = d < 8 ? v[d] : -1;
+  return m >= 0 ? m : shk_xcd_swizzle();
+}
 
 // attr_done: one bit per device ordinal, per kernel instantiation (contexts on several devices, and on several host threads,
 // share the launcher)
@@ -466,9 +486,10 @@ inline hipError_t shk_launch_tile_kernel(void (*k)(NttPassArgs), std::atomic<uin
   // pass 540 -> 325 MB) but measured 3-8 % SLOWER -- the sharers sit 2^k bytes apart, so the concurrently running tiles
   // all map to the same memory channels.
   const uint64_t sharers = last ? 0 : (a.total >> a.log_S);
+  const int swz = shk_xcd_swizzle_of_pass(a.pass_index);
   const bool share = !last && a.tw2 && sharers >= 2 && sharers <= 0xffffffffull && a.log_S >= (uint32_t)log_t + 2 &&
-                     tiles <= 0xffffffffull && shk_xcd_swizzle() == 3;
-  if (shk_xcd_swizzle() && (shk_xcd_swizzle() == 2 || log_t < 2 || share) && tiles >= 64) {
+                     tiles <= 0xffffffffull && swz == 3;
+  if (swz && (swz == 2 || log_t < 2 || share) && tiles >= 64) {
     b.xcd_per = (uint32_t)((tiles + 7) / 8);
     b.sharers = share ? (uint32_t)sharers : 0;
     grid = 8ull * b.xcd_per;
