@@ -375,3 +375,34 @@ def test_proof_stream_round_trips_on_random_shapes():
         branches = [[rng.choice(pool) for _ in range(rng.randrange(0, 6))] for _ in range(rng.randrange(0, 6))]
         assert cz.decompress_branches(cz.compress_branches(branches)) == branches
         assert cz.bin_length(c) == sum(len(x) + (1 if len(x) == 32 else 0) for x in c)
+
+
+def test_hybrid_lane_mapping_is_a_bijection_with_shared_twiddles():
+    """The thread -> row mapping of the matrix-core groups of the hybrid tile pass (csrc/ntt_mfma.hip:HybridLane::ibase), restated:
+    for every tile shape and every group the rule selects, the 4 elements of all threads cover the R x T tile exactly once, and
+    the 32 lanes of a half-wave agree on the low beta bits of their rows -- the bits a level-q twiddle (q <= beta + 1) depends on."""
+    for tile_log in (10, 11):
+        for log_r in range(5, 12):
+            log_t = tile_log - log_r
+            if log_t < 0 or log_t > 5:
+                continue
+            log_w = log_r + log_t - 8
+            for g in range((log_r + 1) // 2):
+                beta = log_r - 2 * (g + 1)
+                if not (0 < beta <= 1 + log_w):
+                    continue
+                seen = set()
+                for tid in range(1 << (log_r + log_t - 2)):
+                    lane, wave = tid & 63, tid >> 6
+                    lane_i = (lane & 31) >> log_t
+                    u = (lane >> 5) | (wave << 1)
+                    hi = lane_i | ((u >> beta) << (5 - log_t))
+                    ibase = (u & ((1 << beta) - 1)) | (hi << (beta + 2))
+                    # the half-wave's shared bits come from (lane bit 5, wave) only
+                    assert ibase & ((1 << beta) - 1) == u & ((1 << beta) - 1)
+                    for h in range(4):
+                        i = ibase | (h << beta)
+                        assert i < (1 << log_r)
+                        seen.add((i, tid & ((1 << log_t) - 1)))
+                assert len(seen) == 1 << (log_r + log_t), (tile_log, log_r, g)
+
