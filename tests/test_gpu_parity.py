@@ -868,10 +868,12 @@ def test_full_size_merkle_2_24_branches_verify(sa):
 
 
 # ---- round 2: reference-independent pins for config 4, config 5 at its size, the new ABI entries -------------------------
-@pytest.mark.parametrize("logn", [22, 24])
+@pytest.mark.parametrize("logn", [19, 21, 22, 23, 24])
 def test_ntt_large_digests_vs_oracle_fixture(sa, logn):
-    """Config 4 (2^24) and 2^22: forward and inverse transforms of the seeded vector against the digests the C oracle
-    produced (tests/golden/ntt_large.json; the oracle is pinned to the live reference up to 2^20)."""
+    """Config 4 (2^24), 2^22 and the three plan shapes no reference digest reaches -- 2^19 (config 5's domain, plan (9, 10)),
+    2^21 (the first three-pass plan) and 2^23 (the domain of the metric's 2^20-step FRI commit, 256 MiB row table): forward and
+    inverse transforms of the seeded vector against the digests the C oracle produced (tests/golden/ntt_large.json; the
+    oracle is pinned to the live reference up to 2^20)."""
     import ctypes
     c = [c for c in load_golden("ntt_large.json")["cases"] if c["logn"] == logn][0]
     L, ctx = sa.lib.lib(), sa.lib.ctx()
