@@ -632,13 +632,11 @@ def main():
         except Exception:
             pass
     passes = int(L.sh_ntt_passes(n, B))
-    path = L.sh_ntt_path_name().decode()
     cfg = {20: "configs[1]", 24: "configs[3]"}.get(args.logn, "2^%d" % args.logn)
     line = {
         "metric": "ntt_field_elements_per_sec", "value": value, "unit": "elements/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU%s)" %
-        (" + i8 MFMA twiddle products" if path != "valu" else ""),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u256 (8 x u32 limbs, integer VALU)",
         "data": "synthetic", "config": {
             "workload": "%s: 2^%d-point NTT + inverse NTT over the MiMC prime, %d vector%s per step per GPU, resident in "
                         "HBM; x == invNTT(NTT(x)) checked on every element and the forward digest against the committed "
@@ -651,9 +649,8 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 64.0 * n * B / passes,
-                     "kernel": "%s (%d launches per 2^%d transform; all passes of both directions averaged)" %
-                               ({"mfma": "ntt_ctile_kernel", "mfma_lds": "ntt_ltile_kernel", "hybrid": "ntt_htile_kernel"}.get(
-                                   path, "ntt_pass_kernel"), passes, args.logn),
+                     "kernel": "ntt_pass_kernel (%d launches per 2^%d transform; all passes of both directions averaged)" %
+                               (passes, args.logn),
                      "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
                      # the same launches by the bytes they really move (PMC traffic per launch / live launch duration): how far
                      # the pass is from the memory roof, as opposed to `frac`, which counts every element once per transform

@@ -46,9 +46,28 @@ B2_HD uint32_t b2_rotr(uint32_t x, int n) {
     B2_G(v3, v4, v9, v14, m[s14], m[s15]);                                           \
   } while (0)
 
+// Device code runs the ten rounds as generated asm blocks (gen_blake2s_asm.py: four columns in lock-step, v_add3_u32, and every
+// instruction in an 8-byte encoding -- + 10 % on the bare hash loop over the compiler's schedule of the C++ rounds below;
+// profiles/r04_blake2s_issue_rate_study.txt).  -DB2_NO_ASM keeps the C++ rounds (A/B builds; the host always uses them).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(B2_NO_ASM)
+#define B2_ASM_ROUNDS 1
+#ifndef B2_ASM_INC
+#define B2_ASM_INC "blake2s_asm.inc"
+#endif
+#include B2_ASM_INC
+#endif
+
 // One compression of a 64-byte block `m` (16 LE words) into chaining value h; t = byte counter,
 // last = final-block flag.
 B2_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t, bool last) {
+#if defined(B2_ASM_ROUNDS)
+  uint32_t v[16] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                    0x510E527Fu ^ t, 0x9B05688Cu, last ? ~0x1F83D9ABu : 0x1F83D9ABu, 0x5BE0CD19u};
+  b2_rounds_asm(v, *reinterpret_cast<const uint32_t(*)[16]>(m));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+  return;
+#else
   uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
   uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
   uint32_t v12 = 0x510E527Fu ^ t, v13 = 0x9B05688Cu, v14 = last ? ~0x1F83D9ABu : 0x1F83D9ABu, v15 = 0x5BE0CD19u;
@@ -70,6 +89,7 @@ B2_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t, bool las
   h[5] ^= v5 ^ v13;
   h[6] ^= v6 ^ v14;
   h[7] ^= v7 ^ v15;
+#endif
 }
 
 B2_HD void b2_init(uint32_t h[8]) {

@@ -11,7 +11,7 @@
 
 #include "../../include/starkhip.h"
 #include "internal.hpp"
-#include "mfma_tw.cuh"
+#include "knobs.hpp"
 
 namespace {
 
@@ -80,8 +80,7 @@ struct NttPlan {
   fp root;                   // effective root (already inverted for inverse transforms)
   std::vector<int> radix;    // log2 radix of each pass
   std::vector<const fp2*> wR;  // per pass: powers of root^(n/R), R/2 entries, as (w, w 2^128) pairs
-  std::vector<fp*> tw2;      // per column pass: [k][j2] copy of tw for the MFMA tile pass (null when it is not used)
-  std::vector<void*> mats;   // per pass: the same powers as MFMA operand images (TwMat[R/2]), null for radix < 2^5
+  std::vector<fp*> tw2;      // per column pass: the same twiddles as rows, tw2[k * S + j2] = g^(j2 k) (null: table too large)
   std::vector<PowTable> tw;  // per column pass d: table of root^(P_d) (times n^-1 on pass 0 when scaled)
   PowTable base;             // unscaled table of root (sh_power_cycle, FRI fold)
   fp* scale = nullptr;       // n^-1 on the device (one-pass scaled plans)
@@ -272,35 +271,6 @@ int upload_table(sh_ctx* c, NttPlan* pl, const std::vector<fp>& host, fp** dev) 
   return SH_OK;
 }
 
-// Which kernels run the tile passes.  Default: the integer-VALU passes (ntt_kernels.cuh).  STARKHIP_NTT_PATH=mfma selects
-// the matrix-core passes (ntt_mfma.hip) wherever they apply: measured within +-8 % of the VALU passes on every shape
-// (DESIGN.md section 5), ahead on large batches, behind on single vectors -- kept selectable, not default.
-// STARKHIP_NTT_PATH=mfma_lds: the LDS-resident 32-column tile with matrix-core register groups (ntt_mfma.hip, second half).
-// STARKHIP_NTT_PATH=hybrid: the VALU plans and tiles, the groups whose twiddles are lane-shared on the matrix cores.
-int mfma_kind() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("STARKHIP_NTT_PATH");
-    v = (e && !strcmp(e, "mfma")) ? 1 : (e && !strcmp(e, "mfma_lds")) ? 2 : (e && !strcmp(e, "hybrid")) ? 3 : 0;
-  }
-  return v;
-}
-bool use_mfma_path() { return mfma_kind() != 0; }
-
-int tw2_max_log() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("STARKHIP_TW2_MAX_LOG");
-    // measured: +5..9 % up to 2^20-entry tables; with the twiddle loads requested ahead of use a 2^23-entry table (256 MiB,
-    // the first pass of the 2^23-point transform of a 2^20-step FRI commit) gains 4 %, a 2^24-entry one (512 MiB) 1.3-2.4 %
-    // (round 3, three rounds in one session) -- taken since the plan cache has a byte budget; 2^25 entries measured 0.7 % behind
-    v = e ? atoi(e) : 24;
-    if (v < 0) v = 0;
-    if (v > 28) v = 28;
-  }
-  return v;
-}
-
 // table of factor * g^e, e < 2^log_order (factor may be null).  Up to 2^direct_log entries the table is stored in full
 // (one load per lookup); larger ones as two halves lo[e & mask] * hi[e >> lb] (one more modmul per lookup).  Full tables
 // above 2^18 entries are expanded on the device from the two halves.
@@ -343,49 +313,11 @@ int build_pow_table(sh_ctx* c, NttPlan* pl, const fp& g, int log_order, const fp
   return SH_OK;
 }
 
-void choose_radices(int log_n, bool few, std::vector<int>* out) {
-  out->clear();
-  // experiments: STARKHIP_NTT_RADICES="10,10" (digits 2..11, at most 4 passes) applies to the sizes it sums to
-  if (const char* e = getenv("STARKHIP_NTT_RADICES")) {
-    std::vector<int> r;
-    int sum = 0;
-    bool ok = true;
-    for (const char* p = e; *p && ok;) {
-      char* end = nullptr;
-      const long v = strtol(p, &end, 10);
-      if (end == p || v < 2 || v > 11) ok = false;
-      r.push_back((int)v);
-      sum += (int)v;
-      p = (*end == ',') ? end + 1 : end;
-      if (*end && *end != ',') ok = false;
-    }
-    if (ok && sum == log_n && r.size() >= 1 && r.size() <= 4) {
-      *out = r;
-      return;
-    }
-  }
-  if (log_n <= 8) {
-    out->push_back(log_n);
-    return;
-  }
-  // Two passes of radix 2^9 / 2^10 (2048-element tiles) where they were measured ahead of three passes of 1024-element
-  // tiles (one inter-pass twiddle modmul and one read + write of the vector fewer per transform;
-  // everything from 2^21 up measured behind).  The matrix-core passes have no such radices: under
-  // STARKHIP_NTT_PATH=mfma the three-pass decomposition stays.
-  if (mfma_kind() == 0 || mfma_kind() == 3) {
-    // measured with the final kernels (wave-local exchanges), forward + inverse, against the three-pass plans of 1024-element
-    // tiles: 2^20 12.3 / 14.1 / 14.5 / 15.5 / 16.1 / 16.5 vs 10.6 / 13.0 / 14.7 / 15.2 / 15.6 / 15.9 G elements/s at 1 / 2 / 4 / 8 / 16 / 32
-    // vectors; 2^18 (9, 9) 14.4 / 17.0 / 18.2 vs 14.3 / 16.7 / 17.7 at 8 / 32 / 128.  `few` (a call of at most 2^21 elements) no
-    // longer selects a different plan; the parameter stays for sizes where it may.
-    (void)few;
-    if (log_n == 17) { *out = {9, 8}; return; }
-    if (log_n == 18) { *out = {9, 9}; return; }
-    if (log_n == 19) { *out = {9, 10}; return; }
-    if (log_n == 20) { *out = {10, 10}; return; }
-  }
-  const int top = (mfma_kind() == 2 && log_n <= 28) ? 7 : 8;  // the LDS-resident matrix-core tile holds at most 2^7 rows
-  const int m = (log_n + top - 1) / top, base = log_n / m, rem = log_n % m;
-  for (int i = 0; i < m; ++i) out->push_back(base + (i < rem ? 1 : 0));
+// the passes of a 2^log_n-point transform (knobs.hpp:shk_choose_radices; one decomposition per size)
+void choose_radices(int log_n, std::vector<int>* out) {
+  int r[4];
+  const int m = shk_choose_radices(log_n, r);
+  out->assign(r, r + m);
 }
 
 constexpr size_t MAX_PLANS = 1024;  // count cap of the plan cache (the byte budget normally binds first)
@@ -460,16 +392,11 @@ int check_root_order(const fp& root, uint64_t n) {
   return fp_eq_canon(h, m1) ? SH_OK : SH_ERR_ROOT_ORDER;
 }
 
-// a call that transforms at most 2^21 elements in all (batch = 0: unknown / not a transform -> the many-vector plan)
-bool few_vectors(uint64_t n, uint64_t batch) { return batch != 0 && batch <= (1ull << 21) / n; }
-
-int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, NttPlan** out) {
+int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, NttPlan** out) {
   std::vector<int> radix;
-  choose_radices(ilog2(n), few, &radix);
-  std::vector<int> other;
-  choose_radices(ilog2(n), !few, &other);
-  // the two decompositions of a size are two plans (own twiddle tables); sizes with one decomposition share it
-  const std::string key = plan_key(root_eff, n, scaled) + ((radix != other && few) ? "f" : "");
+  choose_radices(ilog2(n), &radix);
+  if (radix.empty()) return SH_ERR_UNSUPPORTED;
+  const std::string key = plan_key(root_eff, n, scaled);
   auto it = c->plans.find(key);
   if (it != c->plans.end()) {
     it->second->last_use = ++c->tick;
@@ -500,7 +427,6 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
   int rc = build_pow_table(c, pl, root_eff, pl->log_n, nullptr, &pl->base);
   if (rc == SH_OK && pl->log_n >= 2) {
     std::map<int, const fp2*> wr_by_radix;
-    std::map<int, void*> mats_by_radix;
     int log_P = 0;
     for (size_t d = 0; d < m && rc == SH_OK; ++d) {
       const int r = pl->radix[d];
@@ -520,19 +446,8 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         fp* dev = nullptr;
         rc = upload_table(c, pl, pairs, &dev);
         wr_by_radix[r] = reinterpret_cast<const fp2*>(dev);
-        mats_by_radix[r] = nullptr;
-        // operand images for the matrix-core butterflies (ntt_mfma.hip), only when those passes are selected
-        if (rc == SH_OK && r >= 5 && r <= (mfma_kind() == 3 ? 11 : 8) && use_mfma_path()) {
-          std::vector<TwMat> mm(t.size());
-          for (size_t i = 0; i < t.size(); ++i)
-            if (!shk_build_twmat(t[i], &mm[i])) rc = SH_ERR_INVALID;
-          void* d = nullptr;
-          if (rc == SH_OK) rc = upload_bytes(c, pl, mm.data(), mm.size() * sizeof(TwMat), &d);
-          mats_by_radix[r] = d;
-        }
       }
       pl->wR.push_back(wr_by_radix[r]);
-      pl->mats.push_back(mats_by_radix[r]);
       if (rc == SH_OK && d + 1 < m) {
         PowTable t;
         if (d == 0 && !scaled) {
@@ -548,7 +463,7 @@ int get_plan(sh_ctx* c, const fp& root_eff, uint64_t n, bool scaled, bool few, N
         // above 2^23 entries (STARKHIP_TW2_MAX_LOG) the pass keeps the power-table lookup.
         fp* tw2 = nullptr;
         const int log_S = pl->log_n - log_P - r;
-        if (rc == SH_OK && r + log_S <= tw2_max_log()) {
+        if (rc == SH_OK && r + log_S <= shk_knobs().tw2_max_log) {
           // a failed allocation of the row table (up to 512 MiB) is not fatal: the pass keeps the power-table lookup
           void* dv = nullptr;
           if (plan_alloc(c, pl, sizeof(fp) << (r + log_S), &dv) == SH_OK) {
@@ -585,7 +500,7 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
   const uint64_t n = pl->n;
   if (batch == 0) return SH_OK;
   if (n_in >= n) n_in = 0;
-  if (n_in && (pl->log_n <= 1 || (mfma_kind() == 1 && pl->radix[0] >= 5))) {  // paths without the short-source load
+  if (n_in && pl->log_n <= 1) {  // the tiny transform has no short-source load
     HIP_TRY(c, shk_pad_copy(d_in, d_out, n_in, n, batch, c->stream));
     d_in = d_out;
     n_in = 0;
@@ -631,32 +546,21 @@ int run_ntt(sh_ctx* c, NttPlan* pl, const fp* d_in, fp* d_out, uint32_t batch, u
       for (size_t k = 0; k + 1 < m; ++k) a.dig_log[k] = (uint32_t)pl->radix[k];
       a.scale = (m == 1) ? pl->scale : nullptr;
     }
-    a.mats = use_mfma_path() ? pl->mats[d] : nullptr;
-    a.mfma_kind = (uint32_t)mfma_kind();
     a.pass_index = (uint32_t)d;
-#ifdef SHK_STAMPS
-    {
-      const char* e = getenv("STARKHIP_STAMP_PASS");
-      a.debug = (size_t)(e ? atoi(e) : (int)m - 1) == d;
-      const char* sb = getenv("STARKHIP_STAMP_BASE");  // LDS-tile / hybrid kernels: first recorded workgroup (a multiple of 1024)
-      if (a.debug && sb) a.debug = 1u + (uint32_t)atoi(sb) / 1024u;
-    }
-#endif
-    if (shk_ntt_mfma_supports(r, last, a))
-      HIP_TRY(c, shk_launch_ntt_pass_mfma(r, last, a, c->stream));
-    else
-      HIP_TRY(c, shk_launch_ntt_pass(r, last, a, c->stream));
+    HIP_TRY(c, shk_launch_ntt_pass(r, last, a, c->stream));
     log_P += r;
   }
   return SH_OK;
 }
 
+// (`batch` = the vectors the caller is about to transform; no plan depends on it any more)
 int plan_for(sh_ctx* c, const uint8_t root[32], uint64_t n, bool inverse, NttPlan** out, uint64_t batch = 0) {
+  (void)batch;
   if (!is_pow2(n) || n > (1ull << 32)) return n > (1ull << 32) ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
   fp w = h_from_wire(root);
   SH_TRY(check_root_order(w, n));
   if (inverse) w = h_pow(w, n - 1);  // w^-1: the reversed root list rootz[:0:-1] of fft.py:327
-  return get_plan(c, w, n, inverse, few_vectors(n, batch), out);
+  return get_plan(c, w, n, inverse, out);
 }
 
 uint64_t fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
@@ -1075,10 +979,7 @@ int sh_ctx_create(int device, sh_ctx** out) {
     delete c;
     return SH_ERR_HIP;
   }
-  if (const char* e = getenv("STARKHIP_PLAN_CACHE_MB")) {
-    const long long mb = atoll(e);
-    if (mb >= 0) c->plan_budget = (size_t)mb << 20;
-  }
+  if (shk_knobs().plan_cache_mb >= 0) c->plan_budget = (size_t)shk_knobs().plan_cache_mb << 20;
   *out = c;
   return SH_OK;
 }
@@ -1394,7 +1295,7 @@ int sh_mul_polys(sh_ctx* c, const uint8_t* a, uint64_t n_a, const uint8_t* b, ui
   SH_TRY(enter(c));
   NttPlan *fwd = nullptr, *rev = nullptr;
   SH_TRY(plan_for(c, root, n, false, &fwd, 1));
-  SH_TRY(get_plan(c, h_pow(fwd->root, n - 1), n, false, few_vectors(n, 1), &rev));  // reversed roots, NO 1/n (fft.py:345)
+  SH_TRY(get_plan(c, h_pow(fwd->root, n - 1), n, false, &rev));  // reversed roots, NO 1/n (fft.py:345)
   fp *x = nullptr, *y = nullptr;
   SH_TRY(upload_padded(c, a, n_a, n, 1, sh_ctx::WS_X, &x));
   SH_TRY(upload_padded(c, b, n_b, n, 1, sh_ctx::WS_Y, &y));
@@ -1493,14 +1394,13 @@ int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root
 
 uint32_t sh_ntt_passes(uint64_t n, uint32_t batch) {
   if (!is_pow2(n) || n > (1ull << 32)) return 0;
-  std::vector<int> r;
-  choose_radices(ilog2(n), few_vectors(n, batch), &r);
-  return (uint32_t)r.size();
+  (void)batch;  // one decomposition per size
+  int r[4];
+  return (uint32_t)shk_choose_radices(ilog2(n), r);
 }
 
 const char* sh_ntt_path_name(void) {
-  static const char* const names[] = {"valu", "mfma", "mfma_lds", "hybrid"};
-  return names[mfma_kind()];
+  return "valu";  // the integer-VALU tile passes are the only path (the matrix-core placements: tools/not_kept/mfma)
 }
 
 uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {

@@ -24,11 +24,9 @@ struct NttPassArgs {
   const fp* scale;    // row pass: optional factor applied to every output (n^-1 of a one-pass inverse)
   uint64_t src_n;     // first pass only: the source holds src_n <= n elements per vector, the rest of each vector is zero
                       // (fft_1d's zero padding, fft.py:323-324, never materialised); 0 = the source holds n per vector
-  uint32_t debug;     // diagnostic (SHK_STAMPS) builds only: 1 = this pass records its phase stamps
-  const fp* tw2;      // MFMA column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k); else null
-  const void* mats;   // MFMA passes (ntt_mfma.hip): TwMat[R/2], the operand images of wR[k] (mfma_tw.cuh); else null
+  const fp* tw2;      // column passes: the same twiddles as [k][j2] rows, tw2[k * S + j2] = g^(j2 * k) -- one coalesced load per
+                      // element; null: use the power table (tw_lo / tw_hi)
   uint32_t pass_index; // 0 = the first pass of the transform (experiments: STARKHIP_TILE_LOGS picks a tile size per pass)
-  uint32_t mfma_kind; // with mats: 1 = the register tile (R x 32 in registers), 2 = the LDS-resident R x 32 tile with MFMA groups
   uint32_t xcd_per;   // 0: tile = blockIdx.x.  Else workgroups are dealt to the 8 XCDs round-robin and tile = (blockIdx.x & 7) *
                       // xcd_per + (blockIdx.x >> 3): adjacent tiles run on the SAME XCD (they share 128-byte lines when T < 4)
   uint32_t sharers;   // column passes with xcd_per: the number of (vector, prefix block) pairs = total >> log_S, all of which
@@ -40,11 +38,6 @@ struct NttPassArgs {
 // Launch one tile pass (radix 2^log_R).  Returns hipSuccess or the launch error.
 hipError_t shk_launch_ntt_pass(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
 hipError_t shk_launch_ntt_tiny(const fp* src, fp* dst, uint32_t n, uint32_t batch, const fp* scale, hipStream_t st);
-// ntt_mfma.hip: the same pass with the tile in registers (R rows x 32 columns) and the butterfly products on the matrix
-// cores; supports radix 2^5 .. 2^8, column passes with S >= 32 and every row pass
-bool shk_ntt_mfma_supports(int log_R, bool last, const NttPassArgs& a);
-hipError_t shk_launch_ntt_pass_mfma(int log_R, bool last, const NttPassArgs& a, hipStream_t st);
-constexpr int SHK_TILE_LOG = 10;  // default tile: 1024 elements (32 KiB of LDS, 256 threads) per workgroup -> 5 workgroups per CU
 
 // ---- kernels.hip: conversions, powers, Merkle, FRI fold, sampling, branch gather ------------------
 hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st);

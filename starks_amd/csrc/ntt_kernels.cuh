@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "internal.hpp"
+#include "knobs.hpp"
 
 
 // LDS image of a tile: 32-byte elements, 8 to a 256-byte bank row; the slot inside the row is XOR-ed with
@@ -137,25 +138,10 @@ __device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
   }
 }
 
-// Who does the butterflies of a register group, and which thread holds which elements there: the VALUs with the mapping above
-// (this file), or -- for groups whose twiddles are shared by the 32 lanes of a half-wave -- the matrix cores (ntt_mfma.hip:
-// MfmaLane / HybridLane, whose butterflies() replaces the arithmetic below; everything else of the pass is shared).
-struct ValuLane {
-  static constexpr bool itw_prefetch = true;  // the first inter-pass twiddle is requested ahead of the last group
-  template <int LOG_R, int LOG_T, bool LAST>
-  static constexpr bool group_on_mfma(int) { return false; }
-  template <int LOG_R, int LOG_T, bool LAST>
-  static constexpr int phase(int g) { return tile_phase<LOG_R, LOG_T, LAST>(g); }
-  template <int LOG_R, int LOG_T, bool LAST, int g>
-  static __device__ __forceinline__ uint32_t ibase(uint32_t tid) { return tile_ibase<LOG_R, LOG_T, g>(tid); }
-  __device__ __forceinline__ void stamp(int) const {}  // phase stamps of the diagnostic build (ntt_mfma.hip)
-};
-
 // Register group g: fetch 4 elements (global memory for g == 0, LDS otherwise), do its butterfly levels,
 // and hand the elements to the next group through LDS.
-template <int LOG_R, int LOG_T, bool LAST, int g, class LANE>
-__device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, TileThread& th, uint32_t tid, uint64_t tile0,
-                                          const LANE& ln) {
+template <int LOG_R, int LOG_T, bool LAST, int g>
+__device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, TileThread& th, uint32_t tid, uint64_t tile0) {
   constexpr int R = 1 << LOG_R;
   constexpr int T = 1 << LOG_T;
   constexpr int G = (LOG_R + 1) / 2;
@@ -167,7 +153,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     th.ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
   } else {
     th.t = tid & (T - 1);
-    th.ibase = LANE::template ibase<LOG_R, LOG_T, LAST, g>(tid);
+    th.ibase = tile_ibase<LOG_R, LOG_T, g>(tid);
   }
 
   if (g == 0 || (LAST && g == 1)) {
@@ -227,8 +213,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   };
   // one twiddle is always in flight: the first is requested before the elements are fetched, the next before the current
   // product (the product's inline asm keeps the compiler from moving loads across it, so source order is issue order)
-  constexpr bool on_mfma = LANE::template group_on_mfma<LOG_R, LOG_T, LAST>(g);
-  constexpr int first_tw = on_mfma ? 4 : tw_needed(0) ? 0 : tw_needed(1) ? 1 : tw_needed(2) ? 2 : tw_needed(3) ? 3 : 4;
+  constexpr int first_tw = tw_needed(0) ? 0 : tw_needed(1) ? 1 : tw_needed(2) ? 2 : tw_needed(3) ? 3 : 4;
   fp2 tw_cur, tw_nxt;
   if constexpr (first_tw < 4) tw_cur = tw_load(first_tw);
 
@@ -244,7 +229,6 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
       th.x[0] = th.x[1] = th.x[2] = th.x[3] = fp_zero();
       if (FP_ANY(in)) {  // wave-uniform
         fp x0 = fp_load(a.src + th.sbase + (in ? off : 0));
-        if constexpr (on_mfma) tw_cur = tw_load(0);
         const fp2 tw_b = tw_load(2), tw_c = tw_load(3);  // tw_cur holds butterfly 0's
 #pragma unroll
         for (int w = 0; w < 8; ++w) x0.v[w] = in ? x0.v[w] : 0u;
@@ -285,9 +269,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
   }
 
   // ---- butterfly levels (DIF: a' = a + b, b' = (a - b) * w^((i mod half) * 2^s)) ---------------------
-  if constexpr (on_mfma) {
-    if (!sparse_done) ln.template butterflies<LOG_R, g>(th);
-  } else if (!sparse_done) static_for4([&](auto bc) {
+  if (!sparse_done) static_for4([&](auto bc) {
     constexpr int b = decltype(bc)::value;
     constexpr int q = qhi - (b >> 1), pr = b & 1;
     if constexpr (q >= 0) {
@@ -315,7 +297,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
     for (int h = 0; h < 4; ++h) {
       lds_put_at(lds, lds_slot((th.ibase << LOG_T) | th.t) ^ lds_slot((uint32_t)h << (beta + LOG_T)), th.x[h]);
     }
-    if constexpr (LANE::template phase<LOG_R, LOG_T, LAST>(g) == LANE::template phase<LOG_R, LOG_T, LAST>(g + 1)) {
+    if constexpr (tile_phase<LOG_R, LOG_T, LAST>(g) == tile_phase<LOG_R, LOG_T, LAST>(g + 1)) {
       // the next group's elements were written by lanes of this wave: order the wave's own LDS traffic, nothing more
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -329,8 +311,8 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 #ifndef SHK_NTT_MIN_WAVES
 #define SHK_NTT_MIN_WAVES 4
 #endif
-template <int LOG_R, int LOG_T, bool LAST, class LANE>
-__device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& ln) {
+template <int LOG_R, int LOG_T, bool LAST>
+__device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a) {
   static_assert(LOG_R >= 2 && LOG_R <= 11 && LOG_T >= 0 && LOG_R + LOG_T >= 8 && LOG_R + LOG_T <= 12, "unsupported tile");
   constexpr int G = (LOG_R + 1) / 2;  // register groups (two levels each, the last may have one)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -350,7 +332,6 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& 
     }
   }
   const uint64_t tile0 = tile << LOG_T;
-  ln.stamp(0);
   TileThread th;
   th.t = 0; th.ibase = 0; th.active = false; th.gbase = 0; th.j2 = 0; th.obase = 0; th.sbase = 0;
   // Column passes: the inter-pass twiddles g^(j2 k) of this thread's outputs are requested ahead of their use -- before the
@@ -360,44 +341,35 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& 
   // once, or two, cost a wave per SIMD (106 / 102 VGPRs) and measured slower on single vectors and on 2^24.
   fp itw[4];
   auto itw_load = [&](int h) {
-    const uint32_t i = LANE::template ibase<LOG_R, LOG_T, LAST, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
+    const uint32_t i = tile_ibase<LOG_R, LOG_T, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
     const uint32_t k = __brev(i) >> (32 - LOG_R);
     return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
   };
   auto itw_request = [&]() {
-    if (!LAST && a.tw2 && LANE::itw_prefetch) {  // (matrix-core last groups leave no registers for it)
-      itw[0] = itw_load(0);
-    }
+    if (!LAST && a.tw2) itw[0] = itw_load(0);
   };
   if constexpr (G == 1) {
-    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0, ln);
-    ln.stamp(1);
+    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
     itw_request();
   } else {
-    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0, ln);
-    ln.stamp(1);
+    ntt_group<LOG_R, LOG_T, LAST, 0>(a, lds, th, tid, tile0);
     if constexpr (G == 2) itw_request();
-    ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0, ln);
-    ln.stamp(2);
+    ntt_group<LOG_R, LOG_T, LAST, 1>(a, lds, th, tid, tile0);
     if constexpr (G > 2) {
       if constexpr (G == 3) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0, ln);
-      ln.stamp(3);
+      ntt_group<LOG_R, LOG_T, LAST, 2>(a, lds, th, tid, tile0);
     }
     if constexpr (G > 3) {
       if constexpr (G == 4) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0, ln);
-      ln.stamp(4);
+      ntt_group<LOG_R, LOG_T, LAST, 3>(a, lds, th, tid, tile0);
     }
     if constexpr (G > 4) {
       if constexpr (G == 5) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0, ln);
-      ln.stamp(5);
+      ntt_group<LOG_R, LOG_T, LAST, 4>(a, lds, th, tid, tile0);
     }
     if constexpr (G > 5) {
       if constexpr (G == 6) itw_request();
-      ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0, ln);
-      ln.stamp(6);
+      ntt_group<LOG_R, LOG_T, LAST, 5>(a, lds, th, tid, tile0);
     }
   }
 
@@ -412,56 +384,25 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a, const LANE& 
       if (a.scale) v = fp_mul(v, fp_load(a.scale));
       fp_store(a.dst + th.obase + ((uint64_t)k << a.log_P), v);
     } else {
-      if (!LANE::itw_prefetch && a.tw2 && h == 0) itw[0] = itw_load(0);
       if (a.tw2 && h + 1 < 4) itw[h + 1] = itw_load(h + 1);
       const fp tw = a.tw2 ? itw[h] : tw_lookup(a, th.j2 * k);
       fp v = fp_mul(th.x[h], tw);
       fp_store(a.dst + th.gbase + ((uint64_t)k << a.log_S), v);
     }
   }
-  ln.stamp(G + 1);
 }
 
 template <int LOG_R, int LOG_T, bool LAST>
 __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) ntt_pass_kernel(NttPassArgs a) {
-  ntt_pass_body<LOG_R, LOG_T, LAST>(a, ValuLane{});
+  ntt_pass_body<LOG_R, LOG_T, LAST>(a);
 }
 
 // ---- launching a tile pass (any kernel built on ntt_pass_body) --------------------------------------------------------------
 // Tiles narrower than 128 bytes (T < 4: the big-radix passes) share their cache lines with the neighbouring tile; workgroups
 // are dealt to the 8 XCDs round-robin, so neighbours would sit behind different L2s and every line would be fetched (or
 // written back partially) twice.  Default (1): such launches map adjacent tiles to the same XCD (measured on the T = 1
-// variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ: 0 = never, 2 = every tile pass (measured level for T >= 4),
-// 3 = as 1 plus the sharer-fastest order below.
-inline int shk_xcd_swizzle() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("STARKHIP_XCD_SWZ");
-    v = e ? atoi(e) : 1;
-    if (v < 0 || v > 3) v = 0;
-  }
-  return v;
-}
-// experiments: STARKHIP_XCD_SWZS="2,1,0": the mode of pass 0, 1, 2, ... (-1 / absent = STARKHIP_XCD_SWZ)
-inline int shk_xcd_swizzle_of_pass(uint32_t d) {
-  static int v[8] = {-2, -1, -1, -1, -1, -1, -1, -1};
-  if (v[0] == -2) {
-    int t[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    if (const char* e = getenv("STARKHIP_XCD_SWZS")) {
-      int i = 0;
-      for (const char* p = e; *p && i < 8; ++i) {
-        char* end = nullptr;
-        const long x = strtol(p, &end, 10);
-        if (end == p) break;
-        t[i] = (x >= 0 && x <= 3) ? (int)x : -1;
-        p = (*end == ',') ? end + 1 : end;
-      }
-    }
-    for (int i = 7; i >= 0; --i) v[i] = t[i];
-  }
-  const int m = d < 8 ? v[d] : -1;
-  return m >= 0 ? m : shk_xcd_swizzle();
-}
+// variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ (knobs.hpp): 0 = never, 2 = every tile pass (measured level for
+// T >= 4), 3 = as 1 plus the sharer-fastest order below.
 
 // attr_done: one bit per device ordinal, per kernel instantiation (contexts on several devices, and on several host threads,
 // share the launcher)
@@ -486,7 +427,7 @@ inline hipError_t shk_launch_tile_kernel(void (*k)(NttPassArgs), std::atomic<uin
   // pass 540 -> 325 MB) but measured 3-8 % SLOWER -- the sharers sit 2^k bytes apart, so the concurrently running tiles
   // all map to the same memory channels.
   const uint64_t sharers = last ? 0 : (a.total >> a.log_S);
-  const int swz = shk_xcd_swizzle_of_pass(a.pass_index);
+  const int swz = shk_knobs().xcd_swz;
   const bool share = !last && a.tw2 && sharers >= 2 && sharers <= 0xffffffffull && a.log_S >= (uint32_t)log_t + 2 &&
                      tiles <= 0xffffffffull && swz == 3;
   if (swz && (swz == 2 || log_t < 2 || share) && tiles >= 64) {

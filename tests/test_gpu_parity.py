@@ -1070,24 +1070,6 @@ def test_bench_two_ranks_share_this_gpu(sa, args):
         assert line["scaling"] == "strong" and line["unit"] == "proofs/s"
 
 
-@pytest.mark.parametrize("path", ["mfma", "mfma_lds", "hybrid"])
-def test_mfma_tile_passes_parity(sa, tmp_path, path):
-    """The matrix-core tile passes (csrc/ntt_mfma.hip; the default is the integer-VALU passes) -- STARKHIP_NTT_PATH=mfma: the
-    tile in registers; mfma_lds: the LDS-resident 32-column tile with generated register groups; hybrid: the VALU tile with its
-    shared-twiddle groups on the matrix cores: the NTT golden vectors, every
-    size against the oracle, the 2^22 digest and a FRI + STARK proof, in a child process."""
-    import subprocess, sys
-    from conftest import ROOT
-    env = dict(os.environ, STARKHIP_NTT_PATH=path)
-    sel = ("test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or "
-           "test_randomized_ntt_differential or test_ntt_large_digests_vs_oracle_fixture or test_lde_golden or "
-           "test_fri_proofs_golden or test_stark_proofs_golden or test_device_resident_pipeline")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
-                          "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert " passed" in out.stdout
-
-
 @pytest.mark.parametrize("env", [
     {"STARKHIP_NTT_RADICES": "7,7,6", "STARKHIP_XCD_SWZ": "2"},      # the three-pass plan for 2^20, every tile pass XCD-mapped
     {"STARKHIP_NTT_RADICES": "10,10", "STARKHIP_TILE_LOG_BIG": "12", "STARKHIP_XCD_SWZ": "0"},  # 4096-element tiles

@@ -183,11 +183,13 @@ def test_reference_fft_unit_tests_on_other_fields():
 
 
 def test_generated_asm_includes_are_current(tmp_path):
-    """csrc/fp256_mulasm.inc and fp256_addasm.inc are committed outputs of gen_mulasm.py / gen_addasm.py (whose check() asserts
-    the carry wait states of every generated column): regenerating them must reproduce the committed files byte for byte."""
+    """csrc/fp256_mulasm.inc, fp256_addasm.inc and blake2s_asm.inc are committed outputs of gen_mulasm.py / gen_addasm.py (whose
+    check() asserts the carry wait states of every generated column) and gen_blake2s_asm.py (which executes its own operand
+    wiring against a plain G-by-G BLAKE2s before writing): regenerating them must reproduce the committed files byte for byte."""
     import shutil, subprocess, sys
     csrc = os.path.join(ROOT, "starks_amd", "csrc")
-    for gen, inc in (("gen_mulasm.py", "fp256_mulasm.inc"), ("gen_addasm.py", "fp256_addasm.inc")):
+    for gen, inc in (("gen_mulasm.py", "fp256_mulasm.inc"), ("gen_addasm.py", "fp256_addasm.inc"),
+                     ("gen_blake2s_asm.py", "blake2s_asm.inc")):
         shutil.copy(os.path.join(csrc, gen), tmp_path / gen)
         subprocess.check_call([sys.executable, str(tmp_path / gen)])
         assert (tmp_path / inc).read_bytes() == open(os.path.join(csrc, inc), "rb").read(), inc
@@ -204,41 +206,6 @@ def test_pair_constant_product_on_the_host(tmp_path):
                            os.path.join(ROOT, "starks_amd", "csrc"), src, "-o", str(exe)], stderr=subprocess.DEVNULL)
     out = subprocess.check_output([str(exe)]).decode()
     assert "400000 products, 0 mismatches" in out
-
-
-def test_twiddle_matrix_images(tmp_path):
-    """The MFMA operand images of the matrix-core NTT passes (csrc/mfma_tw.cuh:shk_build_twmat, host code): for every
-    byte k of the multiplicand, the 32 signed digits stored for it sum to w * 256^k (and to -w * 256^k) modulo p, every
-    digit fits an i8, and the (lane, byte) placement is the one the kernels assume (output row i = byte position rho(i))."""
-    import subprocess
-    src = os.path.join(ROOT, "tests", "native", "twmat_dump.cpp")
-    exe = tmp_path / "twmat_dump"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "--offload-arch=gfx950", "-std=c++17", "-I",
-                           os.path.join(ROOT, "starks_amd", "csrc"), src, "-o", str(exe)], stderr=subprocess.DEVNULL)
-    ws = [1, P - 1, 2, 0x80, int("7f" * 32, 16), int("80" * 32, 16) % P, pow(7, (P - 1) // 256, P),
-          pow(7, (P - 1) // (1 << 24), P), 0x0123456789abcdef << 190, P - 12345]
-    out = subprocess.check_output([str(exe)] + ["%064x" % w for w in ws]).decode().split()
-    assert len(out) == len(ws)
-
-    def rho(i):
-        return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3)
-
-    for w, line in zip(ws, out):
-        img = bytes.fromhex(line)
-        assert len(img) == 2048
-        for half, target in ((img[:1024], w), (img[1024:], (P - w) % P)):
-            # lane = i + 32 h holds, at byte j, the digit of position rho(i) of the column kappa = 16 h + j
-            digits = [[0] * 32 for _ in range(32)]  # [kappa][position]
-            for lane in range(64):
-                i, h = lane & 31, lane >> 5
-                for j in range(16):
-                    b = half[16 * lane + j]
-                    digits[16 * h + j][rho(i)] = b - 256 if b >= 128 else b
-            assert sorted(rho(i) for i in range(32)) == list(range(32))
-            for kappa in range(32):
-                val = sum(d << (8 * m) for m, d in enumerate(digits[kappa]))
-                assert (val - target * 256 ** kappa) % P == 0, (hex(w), kappa)
-                assert -128 * ((256**32 - 1) // 255) <= val <= 127 * ((256**32 - 1) // 255)
 
 
 def test_prover_input_shape_errors():
@@ -289,39 +256,6 @@ int main(void) {
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
                            "-o", str(exe), "-L", libdir, "-lstarkhip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     assert subprocess.check_output([str(exe)]).strip() == b"ok"
-
-
-def test_generated_mfma_stages_simulate_correctly():
-    """The scheduled asm stages of the matrix-core tile pass (csrc/gen_bflyasm.py -> mfma_bfly.inc) run in the generator's own
-    instruction-level simulator (64 lanes, MFMA operand layout, carries, the out-of-line rare-carry blocks) and must equal
-    big-integer butterflies (a, b) -> (a + b, (a - b) w) on random and on crafted inputs that take the rare blocks; the
-    committed .inc must be what the generator emits now."""
-    import importlib.util
-    path = os.path.join(ROOT, "starks_amd", "csrc", "gen_bflyasm.py")
-    spec = importlib.util.spec_from_file_location("gen_bflyasm", path)
-    g = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(g)
-    taken = 0
-    for stage, log_r, crafted in ((1, 7, False), (1, 5, True), (2, 8, True), (2, 6, False)):
-        bad, sched = g.selftest(stage, log_r, crafted=crafted)
-        assert bad == 0, (stage, log_r, crafted)
-        assert sched.nops * 7 < sum(i.nslots for i in sched.out), "the schedule lost its interleaving"
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "mfma_bfly.inc")
-        g.emit_inc(out)
-        assert open(out).read() == open(os.path.join(ROOT, "starks_amd", "csrc", "mfma_bfly.inc")).read(), \
-            "mfma_bfly.inc is stale: run python3 starks_amd/csrc/gen_bflyasm.py"
-    # the register groups of the LDS-resident tile (mfma_group.inc): every pattern, twiddles chosen per half-wave
-    for name in g.GROUP_PATTERNS:
-        for crafted in (False, True):
-            bad, sched = g.selftest_group(name, crafted=crafted)
-            assert bad == 0, (name, crafted)
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "mfma_group.inc")
-        g.emit_groups(out)
-        assert open(out).read() == open(os.path.join(ROOT, "starks_amd", "csrc", "mfma_group.inc")).read(), \
-            "mfma_group.inc is stale: run python3 starks_amd/csrc/gen_bflyasm.py"
 
 
 def test_host_generality_outside_the_hot_path():
@@ -377,32 +311,43 @@ def test_proof_stream_round_trips_on_random_shapes():
         assert cz.bin_length(c) == sum(len(x) + (1 if len(x) == 32 else 0) for x in c)
 
 
-def test_hybrid_lane_mapping_is_a_bijection_with_shared_twiddles():
-    """The thread -> row mapping of the matrix-core groups of the hybrid tile pass (csrc/ntt_mfma.hip:HybridLane::ibase), restated:
-    for every tile shape and every group the rule selects, the 4 elements of all threads cover the R x T tile exactly once, and
-    the 32 lanes of a half-wave agree on the low beta bits of their rows -- the bits a level-q twiddle (q <= beta + 1) depends on."""
-    for tile_log in (10, 11):
-        for log_r in range(5, 12):
-            log_t = tile_log - log_r
-            if log_t < 0 or log_t > 5:
-                continue
-            log_w = log_r + log_t - 8
-            for g in range((log_r + 1) // 2):
-                beta = log_r - 2 * (g + 1)
-                if not (0 < beta <= 1 + log_w):
-                    continue
-                seen = set()
-                for tid in range(1 << (log_r + log_t - 2)):
-                    lane, wave = tid & 63, tid >> 6
-                    lane_i = (lane & 31) >> log_t
-                    u = (lane >> 5) | (wave << 1)
-                    hi = lane_i | ((u >> beta) << (5 - log_t))
-                    ibase = (u & ((1 << beta) - 1)) | (hi << (beta + 2))
-                    # the half-wave's shared bits come from (lane bit 5, wave) only
-                    assert ibase & ((1 << beta) - 1) == u & ((1 << beta) - 1)
-                    for h in range(4):
-                        i = ibase | (h << beta)
-                        assert i < (1 << log_r)
-                        seen.add((i, tid & ((1 << log_t) - 1)))
-                assert len(seen) == 1 << (log_r + log_t), (tile_log, log_r, g)
+def test_launch_knobs_are_parsed_once_and_race_free(tmp_path):
+    """csrc/knobs.hpp (every STARKHIP_* launch knob and the plan choice built on them) under ThreadSanitizer: eight host threads
+    take their first look at the knobs at the same moment -- the way the first transforms of two contexts on two threads meet --
+    and ask for the plan of every size; no data race, one object, identical answers.  Also: the environment is read once (a
+    later change is not seen), malformed values fall back to the defaults."""
+    import subprocess
+    exe = tmp_path / "knobs_tsan"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-I",
+                           os.path.join(ROOT, "starks_amd", "csrc"), os.path.join(ROOT, "tests", "native", "knobs_tsan.cpp"),
+                           "-o", str(exe)])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("STARKHIP_")}
+    env["TSAN_OPTIONS"] = "halt_on_error=1 exitcode=66"
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip() == "ok tile_log=10 big=11 logs0=0 swz=1 tw2=24 cache=-1 radices=0 passes20=2 passes24=3"
+    env.update(STARKHIP_NTT_RADICES="7,7,6", STARKHIP_TILE_LOGS="11,9", STARKHIP_XCD_SWZ="7", STARKHIP_TW2_MAX_LOG="20",
+               STARKHIP_TILE_LOG_BIG="13", STARKHIP_PLAN_CACHE_MB="64")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip() == "ok tile_log=10 big=11 logs0=11 swz=0 tw2=20 cache=64 radices=3 passes20=3 passes24=3"
 
+
+def test_library_plan_queries_from_two_threads():
+    """The shipped library: sh_ntt_passes / sh_ntt_path_name (launch-free entries that go through the same knobs and plan
+    choice as a transform) called from two host threads at once agree with the single-threaded answers."""
+    import ctypes, threading
+    from starks_amd import _lib
+    L = _lib.lib()
+    want = [int(L.sh_ntt_passes(1 << lg, 1)) for lg in range(0, 29)]
+    assert want[8] == 1 and want[16] == 2 and want[20] == 2 and want[24] == 3 and want[28] == 4
+    got = [None, None]
+
+    def work(i):
+        got[i] = [[int(L.sh_ntt_passes(1 << lg, 1)) for lg in range(0, 29)] for _ in range(200)]
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(row == want for g in got for row in g)
+    assert L.sh_ntt_path_name() == b"valu"

@@ -19,7 +19,7 @@ if __name__ == "__main__":
         kt = max(glob.glob(root + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
         agg, dur = summarize(cc), durations(kt)
         for k, cs in agg.items():
-            if not any(t in k for t in ("ntt_pass", "ntt_ctile", "ntt_ltile", "ntt_htile", "merkle", "fold", "stark")):
+            if not any(t in k for t in ("ntt_pass", "merkle", "fold", "stark", "sample", "gather", "lincomb")):
                 continue
             ds = dur.get(k, [0])
             print(" %s  n=%d  avg_us=%.1f" % (k[:60], len(ds), sum(ds) / len(ds)))

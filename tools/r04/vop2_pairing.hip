@@ -1,0 +1,85 @@
+// tools/r04/vop2_pairing.hip -- how do the fast ("2x") VOP2 integer ops (v_xor_b32, v_add_u32) and the 1x VOP3 ops
+// (v_alignbit_b32, v_add3_u32) of BLAKE2s share a SIMD's issue slots, depending on their ORDER in the instruction stream?
+// BLAKE2s's G is 10 fast + 4 slow ops (or 8 fast + 2 add3 + 4 alignbit).  If the fast rate needs adjacent fast instructions,
+// the hash kernels should be emitted in lock-step column order.
+//   hipcc -O3 --offload-arch=gfx950 tools/r04/vop2_pairing.hip -o tools/r04/vop2_pairing && tools/r04/vop2_pairing
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+#define X(r) "v_xor_b32 %" #r ", %" #r ", %8\n"
+#define D(r) "v_add_u32 %" #r ", %" #r ", %8\n"
+#define A(r) "v_alignbit_b32 %" #r ", %" #r ", %" #r ", 7\n"
+#define T(r) "v_add3_u32 %" #r ", %" #r ", %8, %8\n"
+#define REGS "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(k)
+
+template <int MODE>
+__global__ void __launch_bounds__(256) kern(uint32_t* out, int iters) {
+  extern __shared__ uint4 pad[];
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (out == nullptr) pad[threadIdx.x] = make_uint4(1, 2, 3, 4);
+  uint32_t r0 = gid, r1 = gid * 3, r2 = gid * 5, r3 = gid * 7, r4 = gid * 11, r5 = gid * 13, r6 = gid * 17, r7 = gid * 19;
+  const uint32_t k = gid | 1;
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 0) asm volatile(X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) : REGS);        // 16 fast
+    if (MODE == 1) asm volatile(A(0) A(1) A(2) A(3) A(4) A(5) A(6) A(7) A(0) A(1) A(2) A(3) A(4) A(5) A(6) A(7) : REGS);        // 16 slow
+    if (MODE == 2) asm volatile(X(0) A(1) X(2) A(3) X(4) A(5) X(6) A(7) X(0) A(1) X(2) A(3) X(4) A(5) X(6) A(7) : REGS);        // alternating
+    if (MODE == 3) asm volatile(X(0) X(1) A(2) A(3) X(4) X(5) A(6) A(7) X(0) X(1) A(2) A(3) X(4) X(5) A(6) A(7) : REGS);        // pairs
+    if (MODE == 4) asm volatile(X(0) X(1) X(2) X(3) A(4) A(5) A(6) A(7) X(0) X(1) X(2) X(3) A(4) A(5) A(6) A(7) : REGS);        // fours
+    if (MODE == 5) asm volatile(X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) A(0) A(1) A(2) A(3) A(4) A(5) A(6) A(7) : REGS);        // eights
+    // one G step per column, four columns, SEQUENTIAL column order: per column T X A D X A (dependent chain inside a column)
+    if (MODE == 6) asm volatile(T(0) X(0) A(0) D(0) X(0) A(0)  T(1) X(1) A(1) D(1) X(1) A(1)  T(2) X(2) A(2) D(2) X(2) A(2)  T(3) X(3) A(3) D(3) X(3) A(3) : REGS);
+    // the same 24 instructions in LOCK-STEP order: T x4, X x4, A x4, D x4, X x4, A x4
+    if (MODE == 7) asm volatile(T(0) T(1) T(2) T(3) X(0) X(1) X(2) X(3) A(0) A(1) A(2) A(3) D(0) D(1) D(2) D(3) X(0) X(1) X(2) X(3) A(0) A(1) A(2) A(3) : REGS);
+    // lock-step over two columns only (pairs)
+    if (MODE == 8) asm volatile(T(0) T(1) X(0) X(1) A(0) A(1) D(0) D(1) X(0) X(1) A(0) A(1)  T(2) T(3) X(2) X(3) A(2) A(3) D(2) D(3) X(2) X(3) A(2) A(3) : REGS);
+    // two adds instead of add3, lock-step over four columns: D D X A D X A
+    if (MODE == 9) asm volatile(D(0) D(1) D(2) D(3) D(0) D(1) D(2) D(3) X(0) X(1) X(2) X(3) A(0) A(1) A(2) A(3) D(0) D(1) D(2) D(3) X(0) X(1) X(2) X(3) A(0) A(1) A(2) A(3) : REGS);
+  }
+  out[gid] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
+}
+
+static const int NINSTR[10] = {16, 16, 16, 16, 16, 16, 24, 24, 24, 28};
+static const char* NAME[10] = {"16 fast (v_xor)", "16 slow (v_alignbit)", "alternating F S F S", "pairs FF SS", "fours FFFF SSSS", "eights",
+                               "G step x4 columns, sequential (T X A D X A per column)", "G step x4 columns, lock-step (T4 X4 A4 D4 X4 A4)",
+                               "G step, lock-step over 2 columns", "G step with two adds for add3, lock-step x4"};
+
+template <int MODE>
+void run(uint32_t* dout, double ghz) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  auto k = kern<MODE>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int iters = 4000;
+  printf("%-62s", NAME[MODE]);
+  for (int w : {1, 2, 4, 8}) {  // waves per SIMD = workgroups (256 threads) per CU
+    const size_t lds = w == 8 ? 0 : (size_t)(160 * 1024 / (w == 1 ? 1 : w)) - (w == 1 ? 4096 : 1024);
+    const int blocks = 256 * w * 4;
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, 0, dout, iters);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (ms < best) best = ms;
+    }
+    // wave-instructions per SIMD = blocks * 4 waves * iters * N / 1024 SIMDs
+    const double instr_per_simd = (double)blocks * 4 * iters * NINSTR[MODE] / 1024.0;
+    printf("  w%d: %5.2f ns/instr (%4.2f cyc @%.1f GHz)", w, best * 1e6 / instr_per_simd, best * 1e6 / instr_per_simd * ghz, ghz);
+  }
+  printf("\n");
+}
+
+int main() {
+  uint32_t* dout;
+  CK(hipMalloc(&dout, 4u * 256 * 256 * 8 * 4));
+  const double ghz = 2.2;
+  run<0>(dout, ghz); run<1>(dout, ghz); run<2>(dout, ghz); run<3>(dout, ghz); run<4>(dout, ghz); run<5>(dout, ghz);
+  run<6>(dout, ghz); run<7>(dout, ghz); run<8>(dout, ghz); run<9>(dout, ghz);
+  return 0;
+}
