@@ -46,28 +46,9 @@ B2_HD uint32_t b2_rotr(uint32_t x, int n) {
     B2_G(v3, v4, v9, v14, m[s14], m[s15]);                                           \
   } while (0)
 
-// Device code runs the ten rounds as generated asm blocks (gen_blake2s_asm.py: four columns in lock-step, v_add3_u32, and every
-// instruction in an 8-byte encoding -- + 10 % on the bare hash loop over the compiler's schedule of the C++ rounds below;
-// profiles/r04_blake2s_issue_rate_study.txt).  -DB2_NO_ASM keeps the C++ rounds (A/B builds; the host always uses them).
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(B2_NO_ASM)
-#define B2_ASM_ROUNDS 1
-#ifndef B2_ASM_INC
-#define B2_ASM_INC "blake2s_asm.inc"
-#endif
-#include B2_ASM_INC
-#endif
-
-// One compression of a 64-byte block `m` (16 LE words) into chaining value h; t = byte counter,
-// last = final-block flag.
-B2_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t, bool last) {
-#if defined(B2_ASM_ROUNDS)
-  uint32_t v[16] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
-                    0x510E527Fu ^ t, 0x9B05688Cu, last ? ~0x1F83D9ABu : 0x1F83D9ABu, 0x5BE0CD19u};
-  b2_rounds_asm(v, *reinterpret_cast<const uint32_t(*)[16]>(m));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
-  return;
-#else
+// The ten rounds in plain C++ (host code; device code where a hash is a serial dependency and few waves are resident: the
+// compiler interleaves the rounds of two independent hashes, which the asm blocks below do not allow).
+B2_HD void b2_compress_cpp(uint32_t h[8], const uint32_t m[16], uint32_t t, bool last) {
   uint32_t v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3], v4 = h[4], v5 = h[5], v6 = h[6], v7 = h[7];
   uint32_t v8 = 0x6A09E667u, v9 = 0xBB67AE85u, v10 = 0x3C6EF372u, v11 = 0xA54FF53Au;
   uint32_t v12 = 0x510E527Fu ^ t, v13 = 0x9B05688Cu, v14 = last ? ~0x1F83D9ABu : 0x1F83D9ABu, v15 = 0x5BE0CD19u;
@@ -89,7 +70,36 @@ B2_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t, bool las
   h[5] ^= v5 ^ v13;
   h[6] ^= v6 ^ v14;
   h[7] ^= v7 ^ v15;
+}
+
+// Throughput form (device only): the ten rounds as generated asm blocks (gen_blake2s_asm.py: four columns in lock-step, plain
+// two-operand adds, a taken branch to the next instruction after every group of rotates -- 51 against 40 G pair-hashes/s for the
+// compiler's schedule of the C++ rounds on the bare hash loop, profiles/r04_blake2s_issue_rate_study.txt).  It wins where
+// many waves hash at once (the wide Merkle levels, the STARK leaf kernels) and loses where one wave per SIMD walks a chain.
+// -DB2_NO_ASM keeps the C++ rounds everywhere (A/B builds).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(B2_NO_ASM)
+#define B2_ASM_ROUNDS 1
+#ifndef B2_ASM_INC
+#define B2_ASM_INC "blake2s_asm.inc"
 #endif
+#include B2_ASM_INC
+#endif
+
+// One compression of a 64-byte block `m` (16 LE words) into chaining value h; t = byte counter, last = final-block flag.
+// THROUGHPUT selects the asm rounds on the device.
+template <bool THROUGHPUT = true>
+B2_HD void b2_compress(uint32_t h[8], const uint32_t m[16], uint32_t t, bool last) {
+#if defined(B2_ASM_ROUNDS)
+  if (THROUGHPUT) {
+    uint32_t v[16] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], 0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                      0x510E527Fu ^ t, 0x9B05688Cu, last ? ~0x1F83D9ABu : 0x1F83D9ABu, 0x5BE0CD19u};
+    b2_rounds_asm(v, *reinterpret_cast<const uint32_t(*)[16]>(m));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] ^= v[i] ^ v[i + 8];
+    return;
+  }
+#endif
+  b2_compress_cpp(h, m, t, last);
 }
 
 B2_HD void b2_init(uint32_t h[8]) {
@@ -105,6 +115,7 @@ B2_HD void b2_init(uint32_t h[8]) {
 
 // digest of the 64-byte message left || right (two 32-byte strings given as 8 LE words each):
 // nodes[i] = blake(nodes[2i] + nodes[2i+1])   (starks/merkle_tree.py:54-55)
+template <bool THROUGHPUT = true>
 B2_HD b2digest b2_hash_pair(const uint32_t left[8], const uint32_t right[8]) {
   uint32_t m[16];
 #pragma unroll
@@ -114,16 +125,17 @@ B2_HD b2digest b2_hash_pair(const uint32_t left[8], const uint32_t right[8]) {
   }
   b2digest d;
   b2_init(d.h);
-  b2_compress(d.h, m, 64, true);
+  b2_compress<THROUGHPUT>(d.h, m, 64, true);
   return d;
 }
 
 // digest of a message of len <= 64 bytes given as zero-padded words (utils.py:75 hashes 32 bytes;
 // the synthetic-input generator hashes 16 bytes)
+template <bool THROUGHPUT = true>
 B2_HD b2digest b2_hash_short(const uint32_t m[16], uint32_t len) {
   b2digest d;
   b2_init(d.h);
-  b2_compress(d.h, m, len, true);
+  b2_compress<THROUGHPUT>(d.h, m, len, true);
   return d;
 }
 

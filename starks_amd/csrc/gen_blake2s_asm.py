@@ -1,15 +1,23 @@
 #!/usr/bin/env python3
 """Generates blake2s_asm.inc: the ten rounds of the BLAKE2s compression function (RFC 7693; blake2s.cuh has the plain C++
-form) as gfx950 inline-asm blocks, four columns (or diagonals) in lock-step.
+form) as gfx950 inline-asm blocks: four columns (or diagonals) in lock-step, plain two-operand adds, and a taken branch to
+the next instruction after every group of rotates.
 
-Why (profiles/r04_blake2s_issue_rate_study.txt; microbenchmarks under tools/r04).  On gfx950 v_add_u32 / v_xor_b32 issue at
-about 0.9 ns per wave-instruction per SIMD and v_alignbit_b32 / v_add3_u32 at about 1.72 ns -- but in a long mixed stream such
-as this hash the fast ones cost 1.5-1.6 ns, whatever their order (runs of 24 fast instructions recover the fast rate in a
-32-instruction loop body and lose it again in a 224-instruction one).  What does help, measured on the bare pair-hash loop
-(tools/blake_occ.hip, G hashes/s): compiler C++ 39.8-40.1; this file's lock-step order with two plain adds 35.7; with
-v_add3_u32 40.8; with the VOP2 instructions in their 8-byte VOP3 encoding 40.2-41.1; with BOTH 43.5-44.2 (every instruction
-of the stream then has the same size) -- the form emitted by default.  In the kernels: Merkle commit of 2^24 leaves 0.678 ->
-0.633 ms, 512 STARK proofs 4732 -> 4835 proofs/s.  --two-adds / --e32 / --align select the other forms for A/B builds.
+Why (profiles/r04_blake2s_issue_rate_study.txt; microbenchmarks under tools/r04).  On gfx950 v_add_u32 / v_xor_b32 (VOP2)
+issue at about 0.9 ns per wave-instruction per SIMD and v_alignbit_b32 / v_add3_u32 (VOP3) at about 1.72 ns -- but in a long
+mixed straight-line stream such as this hash the fast ones cost 1.5-1.6 ns, whatever their order: runs of 24 fast instructions
+recover the fast rate in a 32-instruction LOOP body and lose it again in a 224-instruction one.  The difference is the loop's
+taken branch: a taken `s_branch` in front of a run of fast instructions restores their rate in straight-line code too (an
+`s_nop` in the same place does not).  G is "add add xor | rot | add xor | rot | add add xor | rot | add xor | rot"; with the
+four columns of a half-round in lock-step the fast runs are 12 and 8 instructions long, each started by a branch.
+Bare pair-hash loop (tools/blake_occ.hip, G hashes/s, 4-8 waves per SIMD):
+    compiler, C++ rounds                                   39.8-40.1
+    lock-step, two adds, no branch                          35.7
+    lock-step, v_add3, VOP2 ops in 8-byte encoding          43.5-44.4      (uniform instruction size helps without branches)
+    lock-step, v_add3, branch after the rotates             48.0-48.3
+    lock-step, two adds, branch after the rotates           50.3-51.3      <- emitted by default
+    model: 800 fast + 320 slow instructions at 0.9 / 1.72 ns     51.6
+--add3 / --e64 / --no-branch / --branch-after=... / --align select the other forms for A/B builds.
 
 Each half-round (4 x G) is one asm block: 16 state registers in/out, 8 message words in (24 operands; inline asm allows 30).
 The blocks are not volatile: the compiler may move whole blocks of two independent hashes past each other, never inside.
@@ -35,9 +43,12 @@ COLS = [(0, 4, 8, 12), (1, 5, 9, 13), (2, 6, 10, 14), (3, 7, 11, 15)]
 DIAGS = [(0, 5, 10, 15), (1, 6, 11, 12), (2, 7, 8, 13), (3, 4, 9, 14)]
 
 
-ADD3 = True    # a = a + b + x as one v_add3_u32 (VOP3) instead of two v_add_u32
-E64 = True     # the VOP2 adds / xors in their 8-byte VOP3 encoding
+ADD3 = False   # a = a + b + x as one v_add3_u32 (VOP3) instead of two v_add_u32
+E64 = False    # the VOP2 adds / xors in their 8-byte VOP3 encoding
 ALIGN = False  # every block starts 8-byte aligned (.p2align 3): with four columns per line the 8-byte instructions stay aligned
+BRANCH = 0     # a taken s_branch to the next instruction after every BRANCH lines of a half-round (0 = none)
+BRANCH_OP = "s_branch 0"
+BRANCH_AFTER = (4, 7, 11, 14)  # a taken s_branch to the next instruction after these lines (1-based) of a half-round: the rotates
 
 
 def half_round(groups):
@@ -68,6 +79,20 @@ def half_round(groups):
     each("v_add_u32" + sfx + " %{c}, %{c}, %{d}")
     each("v_xor_b32" + sfx + " %{b}, %{b}, %{c}")
     each("v_alignbit_b32 %{b}, %{b}, %{b}, 7")
+    if BRANCH_AFTER:
+        out = []
+        for i, l in enumerate(lines):
+            out.append(l)
+            if (i + 1) % 4 == 0 and (i + 1) // 4 in BRANCH_AFTER:
+                out.append(BRANCH_OP)
+        return out
+    if BRANCH:
+        out = []
+        for i, l in enumerate(lines):
+            out.append(l)
+            if (i + 1) % (4 * BRANCH) == 0:
+                out.append(BRANCH_OP)
+        return out
     return lines
 
 
@@ -84,10 +109,14 @@ def simulate(m, v):
             ops = list(v) + [m[SIGMA[r][8 * half + i]] for i in range(8)]
             for line in half_round(groups):
                 op, rest = line.split(" ", 1)
+                if op.startswith("s_"):
+                    continue
                 args = [a.strip() for a in rest.split(",")]
                 val = [ops[int(a[1:])] if a.startswith("%") else int(a) for a in args]
                 dst = int(args[0][1:])
                 op = op.replace("_e64", "")
+                if op == "s_branch":
+                    continue
                 if op == "v_add_u32":
                     ops[dst] = (val[1] + val[2]) & M
                 elif op == "v_add3_u32":
@@ -154,14 +183,24 @@ def emit():
 
 
 def main():
-    global ADD3, E64, ALIGN
+    global ADD3, E64, ALIGN, BRANCH, BRANCH_OP, BRANCH_AFTER
     import random
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    if "--two-adds" in sys.argv:
-        ADD3 = False
-    if "--e32" in sys.argv:
-        E64 = False
+    if "--add3" in sys.argv:
+        ADD3 = True
+        BRANCH_AFTER = (3, 6, 9, 12)
+    if "--e64" in sys.argv:
+        E64 = True
+    if "--no-branch" in sys.argv:
+        BRANCH_AFTER = ()
     ALIGN = "--align" in sys.argv
+    for a in sys.argv:
+        if a.startswith("--branch="):
+            BRANCH = int(a.split("=")[1])
+        if a.startswith("--branch-after="):
+            BRANCH_AFTER = tuple(int(x) for x in a.split("=")[1].split(","))
+        if a.startswith("--branch-op="):
+            BRANCH_OP = a.split("=", 1)[1]
     sys.argv = sys.argv[:1] + args
     rng = random.Random(1)
     for _ in range(50):

@@ -135,62 +135,119 @@ __device__ __forceinline__ void block_load_chunks(uint4* lds, const uint4* gsrc,
   for (int c = 0; c < CH; ++c) v[c] = lds[chunk_swz(CH * t + c)];
   __syncthreads();
 }
+// The same hand-over per WAVE: a wave parks the CH chunks of each of its 64 threads in its own LDS slice (64 * CH chunks, which are
+// also contiguous in global memory) and moves them lane-contiguously.  The LDS unit serves one wave's requests in order, so no
+// workgroup barrier is involved and the waves of a workgroup drift apart instead of meeting four times per tile: measured on the
+// leaf kernel without the leaf-level store 409 -> 339 us for 2^24 values (tools/r04/merkle_lab.hip, profiles/r04_merkle_lab.txt).
+// `limit` = valid chunks of the whole block, as above.
+#define SHK_WAVE_SYNC()                                  \
+  do {                                                   \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+template <int CH>
+__device__ __forceinline__ void wave_store_chunks(uint4* lds, uint4* gdst, const uint4 (&v)[CH], uint32_t t, uint32_t limit) {
+  const uint32_t lane = t & 63u, base = (t >> 6) * (64 * CH);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) lds[base + chunk_swz(CH * lane + c)] = v[c];
+  SHK_WAVE_SYNC();
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const uint32_t c = k * 64 + lane;
+    if (base + c < limit) gdst[base + c] = lds[base + chunk_swz(c)];
+  }
+  SHK_WAVE_SYNC();
+}
+template <int CH>
+__device__ __forceinline__ void wave_load_chunks(uint4* lds, const uint4* gsrc, uint4 (&v)[CH], uint32_t t, uint32_t limit) {
+  const uint32_t lane = t & 63u, base = (t >> 6) * (64 * CH);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const uint32_t c = k * 64 + lane;
+    if (base + c < limit) lds[base + chunk_swz(c)] = gsrc[base + c];
+  }
+  SHK_WAVE_SYNC();
+#pragma unroll
+  for (int c = 0; c < CH; ++c) v[c] = lds[base + chunk_swz(CH * lane + c)];
+  SHK_WAVE_SYNC();
+}
 __device__ __forceinline__ uint4 pack4(const uint32_t* w) { return make_uint4(w[0], w[1], w[2], w[3]); }
 __device__ __forceinline__ void unpack4(const uint4& v, uint32_t* w) { w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 
 // One thread per row i of permute4 (merkle_tree.py:11-23): the 4 leaves 4i..4i+3 (wire form) and the three
-// nodes above them.  grid = (ceil(n/4 / 256), batch).
+// nodes above them; a workgroup handles MERKLE_ROWS consecutive tiles of 256 rows.  grid = (ceil(n/4 / (256 * MERKLE_ROWS)), batch).
 // STORE = false skips writing the leaf level (a third of the kernel's traffic): the callers that keep the value array
 // alive next to the tree (FRI rounds, the STARK l tree) re-derive a sampled leaf from its value when they gather branches.
-template <bool RAW, bool STORE>
+// Round 4 (lab: tools/r04/merkle_lab.hip): without the leaf level the pair level goes out per wave (wave_store_chunks) from 16 KiB
+// of LDS: 409 -> 339 us for 2^24 values.  (Two tiles per workgroup, MERKLE_ROWS = 2: 363 -> 334 us in the lab with the leaf
+// level stored, nothing in the library -- 407 vs 411 us -- and slower on small trees: not taken.)
+// WIDE = the launch fills the chip several times over: the hashes use the asm rounds (blake2s.cuh); small launches, where a wave
+// per SIMD walks its three hashes alone, keep the C++ rounds (2^14-step FRI commit: 0.256 ms against 0.276 with asm rounds).
+constexpr int MERKLE_ROWS = 1;
+constexpr uint64_t MERKLE_WIDE_THREADS = 1ull << 19;  // threads per launch from which the asm rounds win (measured between 2^18 and 2^20)
+template <bool RAW, bool STORE, bool WIDE>
 __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, uint64_t n, uint32_t* nodes) {
-  __shared__ uint4 lds[TPB * 8];
+  __shared__ uint4 lds[TPB * (STORE ? 8 : 4)];
   const uint64_t q = n >> 2;
   const uint32_t t = threadIdx.x;
-  const uint64_t row0 = (uint64_t)blockIdx.x * TPB, i = row0 + t, b = blockIdx.y;
-  const bool valid = i < q;
-  const uint32_t rows_here = (uint32_t)(q - row0 < TPB ? q - row0 : TPB);
+  const uint64_t b = blockIdx.y;
   uint32_t* tree = nodes + b * (2 * n) * 8;
-  uint32_t w[4][8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (!valid) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) w[j][k] = 0;
-    } else if (RAW) {
-      load8(reinterpret_cast<const uint32_t*>(leaves) + (b * n + i + j * q) * 8, w[j]);
-    } else {
-      fp v = fp_canon(fp_load(reinterpret_cast<const fp*>(leaves) + b * n + i + j * q));
-      fp_to_wire_words(v, w[j]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
-    }
-  }
-  if (STORE) {
-    uint4 v[8];
+#pragma unroll 1
+  for (int rr = 0; rr < MERKLE_ROWS; ++rr) {
+    const uint64_t row0 = ((uint64_t)blockIdx.x * MERKLE_ROWS + rr) * TPB, i = row0 + t;
+    if (row0 >= q) break;  // whole workgroup
+    const bool valid = i < q;
+    const uint32_t rows_here = (uint32_t)(q - row0 < TPB ? q - row0 : TPB);
+    uint32_t w[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      v[2 * j] = pack4(w[j]);
-      v[2 * j + 1] = pack4(w[j] + 4);
+      if (!valid) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[j][k] = 0;
+      } else if (RAW) {
+        load8(reinterpret_cast<const uint32_t*>(leaves) + (b * n + i + j * q) * 8, w[j]);
+      } else {
+        fp v = fp_canon(fp_load(reinterpret_cast<const fp*>(leaves) + b * n + i + j * q));
+        fp_to_wire_words(v, w[j]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
+      }
     }
-    block_store_chunks<8>(lds, reinterpret_cast<uint4*>(tree + (n + 4 * row0) * 8), v, t, rows_here * 8);
-  }
-  b2digest d0 = b2_hash_pair(w[0], w[1]);
-  b2digest d1 = b2_hash_pair(w[2], w[3]);
-  {
-    uint4 v[4] = {pack4(d0.h), pack4(d0.h + 4), pack4(d1.h), pack4(d1.h + 4)};
-    block_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + (n / 2 + 2 * row0) * 8), v, t, rows_here * 4);
-  }
-  if (!valid) return;
-  b2digest d2 = b2_hash_pair(d0.h, d1.h);
-  store8(tree + (n / 4 + i) * 8, d2.h);
-  if (i == 0) {
-    uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    store8(tree, z);  // nodes[0]: the reference keeps b'' there
+    if (STORE) {
+      uint4 v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[2 * j] = pack4(w[j]);
+        v[2 * j + 1] = pack4(w[j] + 4);
+      }
+      block_store_chunks<8>(lds, reinterpret_cast<uint4*>(tree + (n + 4 * row0) * 8), v, t, rows_here * 8);
+    }
+    b2digest d0 = b2_hash_pair<WIDE>(w[0], w[1]);
+    b2digest d1 = b2_hash_pair<WIDE>(w[2], w[3]);
+    {
+      uint4 v[4] = {pack4(d0.h), pack4(d0.h + 4), pack4(d1.h), pack4(d1.h + 4)};
+      if (STORE)
+        block_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + (n / 2 + 2 * row0) * 8), v, t, rows_here * 4);
+      else
+        wave_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + (n / 2 + 2 * row0) * 8), v, t, rows_here * 4);
+    }
+    if (valid) {
+      b2digest d2 = b2_hash_pair<WIDE>(d0.h, d1.h);
+      store8(tree + (n / 4 + i) * 8, d2.h);
+      if (i == 0) {
+        uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        store8(tree, z);  // nodes[0]: the reference keeps b'' there
+      }
+    }
   }
 }
 
 // Wide levels: one thread reduces 4 adjacent nodes of level L to their parent pair (level L-1) and
 // grandparent (level L-2): every lane busy, three hashes per thread (two independent, one dependent).
 // grid = (ceil(2^(L-2) / 256), batch).
+#ifndef SHK_MID_WAVE
+#define SHK_MID_WAVE 1  // the LDS hand-over per wave (no workgroup barrier), as in the leaf kernel
+#endif
+template <bool WIDE>
 __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64_t n, uint32_t L) {
   __shared__ uint4 lds[TPB * 8];
   const uint64_t cnt = 1ull << (L - 2);  // nodes produced at level L-2, per tree
@@ -199,21 +256,29 @@ __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64
   const uint32_t here = (uint32_t)(cnt - i0 < TPB ? cnt - i0 : TPB);
   uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
   uint4 v[8];
+#if SHK_MID_WAVE
+  wave_load_chunks<8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
+#else
   block_load_chunks<8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
+#endif
   uint32_t w[4][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     unpack4(v[2 * j], w[j]);
     unpack4(v[2 * j + 1], w[j] + 4);
   }
-  b2digest d0 = b2_hash_pair(w[0], w[1]);
-  b2digest d1 = b2_hash_pair(w[2], w[3]);
+  b2digest d0 = b2_hash_pair<WIDE>(w[0], w[1]);
+  b2digest d1 = b2_hash_pair<WIDE>(w[2], w[3]);
   {
     uint4 u[4] = {pack4(d0.h), pack4(d0.h + 4), pack4(d1.h), pack4(d1.h + 4)};
+#if SHK_MID_WAVE
+    wave_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
+#else
     block_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
+#endif
   }
   if (i >= cnt) return;
-  b2digest d2 = b2_hash_pair(d0.h, d1.h);
+  b2digest d2 = b2_hash_pair<WIDE>(d0.h, d1.h);
   store8(tree + (cnt + i) * 8, d2.h);
 }
 
@@ -472,13 +537,22 @@ hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint3
 hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
                          hipStream_t st, bool store_leaves) {
   if (n < 4 || (n & (n - 1)) || batch == 0) return hipErrorInvalidValue;
-  const dim3 lgrid(grid_for(n >> 2), batch);
+  const dim3 lgrid(grid_for(n >> 2, TPB * MERKLE_ROWS), batch);
+  const bool wide = (n >> 2) * batch >= MERKLE_WIDE_THREADS;
+#define SHK_LEAVES(RAW, STORE)                                                                                           \
+  do {                                                                                                                   \
+    if (wide)                                                                                                            \
+      hipLaunchKernelGGL((merkle_leaves_kernel<RAW, STORE, true>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);      \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((merkle_leaves_kernel<RAW, STORE, false>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);     \
+  } while (0)
   if (raw_leaves)
-    hipLaunchKernelGGL((merkle_leaves_kernel<true, true>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
+    SHK_LEAVES(true, true);
   else if (store_leaves)
-    hipLaunchKernelGGL((merkle_leaves_kernel<false, true>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
+    SHK_LEAVES(false, true);
   else
-    hipLaunchKernelGGL((merkle_leaves_kernel<false, false>), lgrid, dim3(TPB), 0, st, d_leaves, n, d_nodes);
+    SHK_LEAVES(false, false);
+#undef SHK_LEAVES
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return shk_merkle_upper_levels(n, batch, d_nodes, st);
@@ -491,7 +565,10 @@ hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes
   int L = (int)logn - 2;
   // wide levels: two levels per launch at full lane efficiency, while a level still fills the chip
   while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << 15)) {
-    hipLaunchKernelGGL(merkle_mid_kernel, dim3(grid_for(1ull << (L - 2)), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
+    if (((1ull << (L - 2)) * batch) >= MERKLE_WIDE_THREADS / 2)
+      hipLaunchKernelGGL(merkle_mid_kernel<true>, dim3(grid_for(1ull << (L - 2)), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
+    else
+      hipLaunchKernelGGL(merkle_mid_kernel<false>, dim3(grid_for(1ull << (L - 2)), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     L -= 2;

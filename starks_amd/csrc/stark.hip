@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64) stark_scalars_kernel(const uint32_t* mnode
     for (int j = 9; j < 16; ++j) m[j] = 0;
     const uint32_t digit = t < 4 ? t + 1 : t - 4;  // stark.py:118-125
     m[8] = 0x30u | (0x78u << 8) | (0x30u << 16) | ((0x30u + digit) << 24);  // "0x0<digit>"
-    b2digest d = b2_hash_short(m, 36);
+    b2digest d = b2_hash_short<false>(m, 36);  // a handful of lanes: latency, not throughput
     ks[t] = fp_from_wire_words(d.h);
   }
   __syncthreads();

@@ -5,5 +5,5 @@ tail -1 gpurun_out/abm_parity.log
 for rep in 1 2; do for L in A B; do
   if [ $L = B ]; then export STARKHIP_LIB=$PWD/starks_amd/libstarkhip_ab.so; else unset STARKHIP_LIB; fi
   echo "== lib $L (round $rep)"
-  timeout -k 10 100 python3 tools/merkle_time.py && timeout -k 10 200 python3 tools/fri_profile.py 20:1 14:1 && timeout -k 10 200 python3 bench.py --workload c5 --no-cpu-baseline --no-extras | grep -o '"value": [0-9.]*' || exit 1
+  timeout -k 10 100 python3 tools/merkle_time.py && timeout -k 10 200 python3 tools/fri_profile.py 20:1 14:1 && timeout -k 10 200 python3 bench.py --workload c5 --no-cpu-baseline --no-extras 2>/dev/null | grep -o '"value": [0-9.]*' || exit 1
 done; done

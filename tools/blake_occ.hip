@@ -10,6 +10,9 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
+#ifndef OCC_UNROLL
+#define OCC_UNROLL 1
+#endif
 template <int ILP>
 __global__ void __launch_bounds__(256) k_blake(const fp* in, fp* out) {
   extern __shared__ uint4 pad[];
@@ -21,6 +24,7 @@ __global__ void __launch_bounds__(256) k_blake(const fp* in, fp* out) {
   for (int j = 0; j < ILP; ++j)
 #pragma unroll
     for (int k = 0; k < 8; ++k) d[j].h[k] = in[gid * 2].v[k] + j;
+#pragma unroll OCC_UNROLL
   for (int i = 0; i < 64 / ILP; ++i)
 #pragma unroll
     for (int j = 0; j < ILP; ++j) d[j] = b2_hash_pair(d[j].h, b.v);
