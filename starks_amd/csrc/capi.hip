@@ -594,6 +594,9 @@ int fri_validate(uint64_t n, uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t 
   return SH_OK;
 }
 
+// vals / tree: round 0 (the evaluations and their tree); next / tree2: the arenas of the later rounds, round r >= 1 at element
+// offset batch * (n/4 + n/16 + ... + n/4^(r-1)) -- every round's column and tree stay until the commit's single sampling +
+// gather pass at the end.
 struct FriBuffers {
   fp *vals, *next;
   uint32_t *tree, *tree2, *ys;
@@ -601,10 +604,10 @@ struct FriBuffers {
 int fri_buffers(sh_ctx* c, uint64_t n, uint32_t batch, uint32_t samples, FriBuffers* b) {
   void *va, *vb, *ta, *tb, *misc;
   SH_TRY(ws_get(c, sh_ctx::WS_COL_A, (size_t)batch * n * sizeof(fp), &va));
-  SH_TRY(ws_get(c, sh_ctx::WS_COL_B, (size_t)batch * (n / 4 + 1) * sizeof(fp), &vb));
+  SH_TRY(ws_get(c, sh_ctx::WS_COL_B, (size_t)batch * (n / 3 + 2) * sizeof(fp), &vb));
   SH_TRY(ws_get(c, sh_ctx::WS_TREE_A, (size_t)batch * 2 * n * 32, &ta));
-  SH_TRY(ws_get(c, sh_ctx::WS_TREE_B, (size_t)batch * 2 * (n / 4 + 1) * 32, &tb));
-  SH_TRY(ws_get(c, sh_ctx::WS_MISC, (size_t)batch * (samples > 40 ? samples : 40) * 4 + 64, &misc));
+  SH_TRY(ws_get(c, sh_ctx::WS_TREE_B, (size_t)batch * 2 * (n / 3 + 2) * 32, &tb));
+  SH_TRY(ws_get(c, sh_ctx::WS_MISC, (size_t)batch * ((samples > 40 ? samples : 40) + 40 * SHK_FRI_MAX_ROUNDS) * 4 + 64, &misc));
   b->vals = reinterpret_cast<fp*>(va);
   b->next = reinterpret_cast<fp*>(vb);
   b->tree = reinterpret_cast<uint32_t*>(ta);
@@ -625,7 +628,16 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   uint32_t round = 0;
   const fp inv_i = h_pow(pl->root, 3 * (n / 4));  // I^-1 = I^3, I = root^(n/4)
   const fp inv_4 = h_inv(fp_from_u32(4u));
+  FriSampleArgs sa;
+  memset(&sa, 0, sizeof sa);
+  sa.batch = batch;
+  sa.exclude = exclude;
+  sa.ys = fb.ys;
+  sa.proof = d_proof;
+  sa.proof_stride = stride;
+  uint32_t ys_off = 0;
   while (md > 16) {
+    if (round >= SHK_FRI_MAX_ROUNDS) return SH_ERR_UNSUPPORTED;
     const uint32_t s = round == 0 ? samples : 40;
     if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream, false));  // m = merkelize(values), fri.py:224
     FoldArgs fa;
@@ -644,32 +656,35 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
     fa.inv_4 = inv_4;
     HIP_TRY(c, shk_fri_fold(fa, c->stream));                                   // column, fri.py:235-242
     HIP_TRY(c, shk_merkelize(next, false, nn / 4, batch, tree2, c->stream, false));   // m2, fri.py:243
-    SampleArgs sa;
-    memset(&sa, 0, sizeof sa);
-    sa.values = vals;
-    sa.column = next;
-    sa.nodes_m = tree;
-    sa.nodes_m2 = tree2;
-    sa.n = nn;
-    sa.batch = batch;
-    sa.samples = s;
-    sa.exclude = exclude;
-    sa.ys = fb.ys;
-    sa.proof = d_proof;
-    sa.proof_stride = stride;
-    sa.round_off = off;
-    HIP_TRY(c, shk_fri_sample_and_gather(sa, c->stream));                      // fri.py:246-254
+    // fri.py:246-254 (the 40 sampled rows and their 5 branches each): recorded, done for all rounds at the end
     const uint64_t lg = (uint64_t)ilog2(nn);
+    FriRound& r = sa.r[round];
+    r.values = vals;
+    r.column = next;
+    r.nodes_m = tree;
+    r.nodes_m2 = tree2;
+    r.n = nn;
+    r.round_off = off;
+    r.samples = s;
+    r.ys_off = ys_off;
+    r.work_begin = sa.work_total;
+    sa.work_total += ((uint64_t)s * ((lg - 1) + 4 * (lg + 1)) + 1) * batch;
+    ys_off += batch * s;
     off += 32 + (uint64_t)s * 32 * ((lg - 1) + 4 * (lg + 1));
     // Next round (fri.py:260-266): the reference inverse-transforms the column over root^4 and transforms it
-    // back, which is the identity on the column; its tree m of round r+1 is this round's m2.
-    std::swap(vals, next);
-    std::swap(tree, tree2);
+    // back, which is the identity on the column; its tree m of round r+1 is this round's m2.  The column and its tree
+    // stay where they are (the arenas), the round after writes behind them.
+    vals = next;
+    tree = tree2;
+    next = next + (size_t)batch * (nn / 4);
+    tree2 = tree2 + (size_t)batch * 2 * (nn / 4) * 8;
     have_tree = true;
     nn >>= 2;
     md >>= 2;
     ++round;
   }
+  sa.rounds = round;
+  HIP_TRY(c, shk_fri_sample_and_gather_all(sa, c->stream));
   HIP_TRY(c, shk_fri_final(vals, nn, batch, d_proof, stride, off, c->stream));  // fri.py:212-214
   return SH_OK;
 }

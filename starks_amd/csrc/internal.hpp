@@ -76,22 +76,32 @@ struct FoldArgs {
   fp inv_4;                // 4^-1
 };
 hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st);
-// ys[b][s] from the column tree's root (utils.py:60-90), then copy 5 branches per sample into the proof
-struct SampleArgs {
+// Query sampling + branch gather of ALL rounds of a FRI commit in two launches (fri.py:246-254 per round): every round keeps
+// its values and its tree until the end of the commit, so nothing on the serial chain tree -> challenge -> fold -> tree waits
+// for the 40 x 5 branch copies of the round before.
+constexpr uint32_t SHK_FRI_MAX_ROUNDS = 12;  // domain <= 2^26 (the column of round 0 must stay below 2^24 rows, utils.py:69)
+struct FriRound {
   const fp* values;          // [batch][n]   the values under nodes_m  (leaves are re-derived from them)
   const fp* column;          // [batch][n/4] the values under nodes_m2
   const uint32_t* nodes_m;   // [batch][2n][8]   tree of the values
   const uint32_t* nodes_m2;  // [batch][2q][8]   tree of the column (q = n/4)
   uint64_t n;
-  uint32_t batch;
+  uint64_t round_off;        // byte offset of this round inside a proof
   uint32_t samples;
+  uint32_t ys_off;           // this round's slice of the ys scratch: ys[(ys_off + b * samples) ...]
+  uint64_t work_begin;       // gather: first work item of this round (prefix sum of (samples * slots + 1) * batch)
+};
+struct FriSampleArgs {
+  FriRound r[SHK_FRI_MAX_ROUNDS];
+  uint32_t rounds;
+  uint32_t batch;
   uint32_t exclude;
-  uint32_t* ys;              // [batch][samples] scratch
+  uint32_t* ys;              // scratch, sum over rounds of batch * samples
   uint8_t* proof;            // [batch][proof_stride] device proof buffers
   uint64_t proof_stride;
-  uint64_t round_off;        // byte offset of this round inside a proof
+  uint64_t work_total;
 };
-hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st);
+hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st);
 // ys[b][0..samples) = get_pseudorandom_indices(node 1 of tree b, modulus, samples, exclude) (utils.py:60-90);
 // trees are tree_words u32 apart
 hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint32_t modulus, uint32_t batch,

@@ -395,18 +395,13 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
 // get_pseudorandom_indices(root, modulus, samples, exclude_multiples_of) (utils.py:60-90): one QUAD of lanes per proof.
 // data = root, then data += blake(data[-32:]) (utils.py:74-75): a serial chain, so each 32-byte block is hashed
 // with the low-latency quad-lane BLAKE2s; after block k lane q holds words q and 4+q = samples 8k+q and 8k+4+q.
-__global__ void __launch_bounds__(64) sample_indices_kernel(const uint32_t* nodes, uint64_t tree_words, uint32_t modulus,
-                                                            uint32_t batch, uint32_t samples, uint32_t exclude,
-                                                            uint32_t* ys_out) {
-  __shared__ __attribute__((aligned(16))) uint32_t slots[16 * 16];
+__device__ __forceinline__ void sample_indices_quad(uint32_t* slots, const uint32_t* root, bool live, uint32_t modulus, uint32_t samples,
+                                                    uint32_t exclude, uint32_t* ys) {
   const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
-  const uint32_t b = blockIdx.x * 16 + quad;
-  const bool live = b < batch;
   b2q_addr ad;
   b2q_addr_init(ad, quad * 64, q);
   uint32_t w_lo = 0, w_hi = 0;
   if (live) {
-    const uint32_t* root = nodes + (uint64_t)b * tree_words + 8;  // entropy = node 1 of proof b's tree
     w_lo = root[q];
     w_hi = root[4 + q];
   }
@@ -414,7 +409,6 @@ __global__ void __launch_bounds__(64) sample_indices_kernel(const uint32_t* node
   slot[8 + q] = 0;   // a 32-byte message: words 8..15 are zero padding
   slot[12 + q] = 0;
   const uint32_t real = exclude ? (uint32_t)(((uint64_t)modulus * (exclude - 1)) / exclude) : modulus;
-  uint32_t* ys = ys_out + (uint64_t)b * samples;
   const uint32_t blocks = (samples + 7) / 8;
   for (uint32_t k = 0; k < blocks; ++k) {
     if (live) {
@@ -435,18 +429,45 @@ __global__ void __launch_bounds__(64) sample_indices_kernel(const uint32_t* node
     __syncthreads();
   }
 }
-// mk_branch (merkle_tree.py:59-68) for the 5 branches of every sample, written into the flat proof.
-__global__ void __launch_bounds__(TPB) fri_gather_kernel(SampleArgs a, uint32_t l1, uint32_t l2) {
-  const uint64_t q = a.n >> 2;
+__global__ void __launch_bounds__(64) sample_indices_kernel(const uint32_t* nodes, uint64_t tree_words, uint32_t modulus,
+                                                            uint32_t batch, uint32_t samples, uint32_t exclude,
+                                                            uint32_t* ys_out) {
+  __shared__ __attribute__((aligned(16))) uint32_t slots[16 * 16];
+  const uint32_t b = blockIdx.x * 16 + (threadIdx.x >> 2);
+  const bool live = b < batch;
+  sample_indices_quad(slots, nodes + (uint64_t)b * tree_words + 8, live, modulus, samples, exclude,  // entropy = node 1 of proof b's tree
+                      ys_out + (uint64_t)b * samples);
+}
+// all rounds of a commit: blockIdx.y = round; entropy = the root of the round's column tree (fri.py:246)
+__global__ void __launch_bounds__(64) fri_sample_all_kernel(FriSampleArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t slots[16 * 16];
+  const FriRound& r = a.r[blockIdx.y];
+  const uint32_t b = blockIdx.x * 16 + (threadIdx.x >> 2);
+  const bool live = b < a.batch;
+  const uint64_t q = r.n >> 2;
+  sample_indices_quad(slots, r.nodes_m2 + (uint64_t)b * (2 * q * 8) + 8, live, (uint32_t)q, r.samples, a.exclude,
+                      a.ys + r.ys_off + (uint64_t)b * r.samples);
+}
+// mk_branch (merkle_tree.py:59-68) for the 5 branches of every sample of every round, written into the flat proofs.
+__global__ void __launch_bounds__(TPB) fri_gather_all_kernel(FriSampleArgs a) {
+  const uint64_t g0 = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g0 >= a.work_total) return;
+  uint32_t ri = 0;
+#pragma unroll 1
+  while (ri + 1 < a.rounds && g0 >= a.r[ri + 1].work_begin) ++ri;
+  const FriRound& rd = a.r[ri];
+  const uint64_t g = g0 - rd.work_begin;
+  const uint64_t q = rd.n >> 2;
+  uint32_t l1 = 1;
+  while ((1ull << (l1 - 1)) < rd.n) ++l1;  // log2(n) + 1
+  const uint32_t l2 = l1 - 2;              // log2(n/4) + 1
   const uint32_t per_sample = l2 + 4 * l1;
-  const uint64_t per_proof = (uint64_t)a.samples * per_sample + 1;  // +1: the root2 slot
-  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= per_proof * a.batch) return;
+  const uint64_t per_proof = (uint64_t)rd.samples * per_sample + 1;  // +1: the root2 slot
   const uint64_t b = g / per_proof;
   uint64_t r = g - b * per_proof;
-  uint32_t* out = reinterpret_cast<uint32_t*>(a.proof + b * a.proof_stride + a.round_off);
-  const uint32_t* m = a.nodes_m + b * 2 * a.n * 8;
-  const uint32_t* m2 = a.nodes_m2 + b * 2 * q * 8;
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.proof + b * a.proof_stride + rd.round_off);
+  const uint32_t* m = rd.nodes_m + b * 2 * rd.n * 8;
+  const uint32_t* m2 = rd.nodes_m2 + b * 2 * q * 8;
   uint32_t w[8];
   if (r == 0) {
     load8(m2 + 8, w);
@@ -455,16 +476,16 @@ __global__ void __launch_bounds__(TPB) fri_gather_kernel(SampleArgs a, uint32_t 
   }
   r -= 1;
   const uint32_t s = (uint32_t)(r / per_sample), slot = (uint32_t)(r - (uint64_t)s * per_sample);
-  const uint32_t y = a.ys[b * a.samples + s];
+  const uint32_t y = a.ys[rd.ys_off + b * rd.samples + s];
   const uint32_t* tree;
   const fp* vals;
   uint64_t leaves, index;
   uint32_t lev;
   if (slot < l2) {
-    tree = m2; vals = a.column + b * q; leaves = q; index = y; lev = slot;
+    tree = m2; vals = rd.column + b * q; leaves = q; index = y; lev = slot;
   } else {
     const uint32_t br = (slot - l2) / l1;
-    tree = m; vals = a.values + b * a.n; leaves = a.n; index = y + q * br; lev = (slot - l2) - br * l1;
+    tree = m; vals = rd.values + b * rd.n; leaves = rd.n; index = y + q * br; lev = (slot - l2) - br * l1;
   }
   const uint64_t ld4 = leaves >> 2;  // get_index_in_permuted (merkle_tree.py:26-33)
   const uint64_t pi = index / ld4 + 4 * (index % ld4);
@@ -595,15 +616,12 @@ hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint
                      samples, exclude, d_ys);
   return hipGetLastError();
 }
-hipError_t shk_fri_sample_and_gather(const SampleArgs& a, hipStream_t st) {
-  hipError_t e = shk_sample_indices(a.nodes_m2, 2 * (a.n >> 2) * 8, (uint32_t)(a.n >> 2), a.batch, a.samples, a.exclude,
-                                    a.ys, st);  // entropy = root of the column tree
+hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st) {
+  if (!a.rounds || !a.batch) return hipSuccess;
+  hipLaunchKernelGGL(fri_sample_all_kernel, dim3((a.batch + 15) / 16, a.rounds), dim3(64), 0, st, a);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  uint32_t l1 = 1, l2;
-  while ((1ull << (l1 - 1)) < a.n) ++l1;  // log2(n) + 1
-  l2 = l1 - 2;                            // log2(n/4) + 1
-  const uint64_t work = ((uint64_t)a.samples * (l2 + 4 * l1) + 1) * a.batch;
-  hipLaunchKernelGGL(fri_gather_kernel, dim3(grid_for(work)), dim3(TPB), 0, st, a, l1, l2);
+  hipLaunchKernelGGL(fri_gather_all_kernel, dim3(grid_for(a.work_total)), dim3(TPB), 0, st, a);
   return hipGetLastError();
 }
 hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,
