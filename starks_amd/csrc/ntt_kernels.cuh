@@ -23,6 +23,15 @@
 #include "knobs.hpp"
 
 
+// A/B knobs of round 4: non-temporal loads in the first pass of the long transforms (the 2048-element tiles of
+// radix 2^8: ntt_pass_kernel<8, 3, false>), whose 512 MiB row table (SHK_NT_TW2) and whose own elements (SHK_NT_ELEM) are read once.
+#ifndef SHK_NT_TW2
+#define SHK_NT_TW2 0
+#endif
+#ifndef SHK_NT_ELEM
+#define SHK_NT_ELEM 0
+#endif
+
 // LDS image of a tile: 32-byte elements, 8 to a 256-byte bank row; the slot inside the row is XOR-ed with
 // the higher index bits so that any power-of-two stride between lanes spreads over all 8 slots.
 __host__ __device__ constexpr uint32_t lds_slot(uint32_t e) {
@@ -259,7 +268,10 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const uint32_t i = th.ibase | ((uint32_t)h << beta);
-        th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
+        if constexpr (SHK_NT_ELEM && LOG_R == 8 && LOG_T == 3 && !LAST)
+          th.x[h] = fp_load_nt(a.src + th.gbase + ((uint64_t)i << a.log_S));
+        else
+          th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
       }
     }
   } else {
@@ -343,6 +355,7 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a) {
   auto itw_load = [&](int h) {
     const uint32_t i = tile_ibase<LOG_R, LOG_T, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
     const uint32_t k = __brev(i) >> (32 - LOG_R);
+    if constexpr (SHK_NT_TW2 && LOG_R == 8 && LOG_T == 3 && !LAST) return fp_load_nt(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
     return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
   };
   auto itw_request = [&]() {

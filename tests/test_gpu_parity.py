@@ -1070,6 +1070,41 @@ def test_bench_two_ranks_share_this_gpu(sa, args):
         assert line["scaling"] == "strong" and line["unit"] == "proofs/s"
 
 
+@pytest.mark.parametrize("workload", ["ntt", "c5"])
+def test_bench_rccl_collectives_with_one_rank(sa, workload):
+    """The RCCL path (backend nccl) before its first N > 1 run on the driver's 8-GPU node: bench.py launched by
+    torch.distributed.run with ONE rank and BENCH_FORCE_DIST=1, so that init_process_group("nccl", device_id=...), the barrier,
+    the MAX / MIN all_reduce of device tensors and the all_gather of the proof headers on device buffers all run over RCCL.
+    One JSON line, check.ok, and the gathered headers equal the ones the gloo control plane delivers for the same units."""
+    import json, subprocess, sys
+    from conftest import ROOT
+
+    def run(backend):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(29500 + os.getpid() % 2000 + (7 if backend == "gloo" else 0)), os.path.join(ROOT, "bench.py"),
+               "--gpus", "1", "--backend", backend, "--quick", "--no-cpu-baseline", "--no-extras", "--workload", workload]
+        if workload == "ntt":
+            cmd += ["--steps", "2", "--warmup", "1", "--logn", "14"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        return json.loads(lines[0])
+
+    line = run("nccl")
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    c5 = line["c5"]
+    assert c5["check"]["ok"] is True and c5["units_per_rank"] == [16]
+    assert c5["check"]["rank0"]["batch_equals_single"] is True and c5["check"]["rank0"]["verifies"] is True
+    if workload == "ntt":
+        assert line["check"]["roundtrip_ok"] is True
+    other = run("gloo")
+    assert other["c5"]["headers_sha256"] == c5["headers_sha256"]
+
+
 @pytest.mark.parametrize("env", [
     {"STARKHIP_NTT_RADICES": "7,7,6", "STARKHIP_XCD_SWZ": "2"},      # the three-pass plan for 2^20, every tile pass XCD-mapped
     {"STARKHIP_NTT_RADICES": "10,10", "STARKHIP_TILE_LOG_BIG": "12", "STARKHIP_XCD_SWZ": "0"},  # 4096-element tiles

@@ -41,5 +41,16 @@ if __name__ == "__main__":
     if last:
         res["algorithmic_bytes_per_launch"] = 64.0 * (1 << logn) * vectors / res["passes_per_transform"]
         res["traffic_over_algorithmic"] = res["ntt_pass_kernel_mean_hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+    if len(sys.argv) > 7:  # directory of a --pmc SQ_INSTS_VALU ... run of the same command
+        V = per_kernel(sys.argv[7], "SQ_INSTS_VALU")
+        tot = 0.0
+        for k in res["kernels"]:
+            if k in V:
+                res["kernels"][k]["valu_wave_instructions_per_launch"] = sum(V[k]) / len(V[k])
+                tot += res["kernels"][k]["valu_wave_instructions_per_launch"] * res["kernels"][k]["launches"]
+        if last and tot:
+            # wave-instructions of all launches x 64 lanes / elements transformed (each transform = n * vectors elements)
+            res["lane_instructions_per_element_per_transform"] = tot * 64.0 / (last * (1 << logn) * vectors)
+            res["valu_source"] = "rocprofv3 --pmc SQ_INSTS_VALU (wave-instructions per dispatch), same command"
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
