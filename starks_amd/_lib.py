@@ -178,11 +178,16 @@ class PinnedBuffer(object):
         self.view = (ctypes.c_char * nbytes).from_address(self.ptr.value)
 
     def close(self):
-        """Frees the buffer; `view` is dropped with it.  After `_lib.close()` the context (and with it every pinned
-        allocation's owner) is gone: nothing is re-created here just to free."""
+        """Frees the buffer; `view` is dropped with it.  The page-locked allocation belongs to the process, not to the context
+        (sh_ctx_destroy frees no caller buffers): after `_lib.close()` it is released through the context-less form
+        sh_host_free(NULL, ptr) instead of being leaked."""
         ptr, self.ptr, self.view = self.ptr, None, None
-        if ptr and _ctx is not None:
-            check(lib().sh_host_free(_ctx, ptr), "sh_host_free")
+        if ptr:
+            rc = lib().sh_host_free(_ctx, ptr)  # _ctx may be None
+            if _ctx is not None:
+                check(rc, "sh_host_free")
+            elif rc != 0:
+                raise StarkHipError(rc, "sh_host_free", "")
 
     def __del__(self):  # pragma: no cover
         try:
@@ -199,6 +204,8 @@ def to_wire(values, modulus=MIMC_P):
 
     One C-level `int.to_bytes` per value and one join (0.3 us per value; the per-value slice assignment this replaces
     took twice that); plain ints in range -- the common case -- take the first branch without any per-value test."""
+    if not isinstance(values, (list, tuple)):
+        values = list(values)  # an iterator must not be half consumed by the fast path before the general one starts over
     try:
         return b"".join([v.to_bytes(32, "big") for v in values])
     except (AttributeError, OverflowError, TypeError):

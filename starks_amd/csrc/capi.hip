@@ -1074,7 +1074,13 @@ int sh_host_alloc(sh_ctx* c, uint64_t bytes, void** hptr) {
   return SH_OK;
 }
 int sh_host_free(sh_ctx* c, void* hptr) {
-  if (!c) return SH_ERR_INVALID;
+  if (!c) {
+    // the context that allocated it is gone (sh_ctx_destroy frees no caller buffers): a pinned buffer belongs to the process,
+    // so it can still be released -- device-wide, since no stream is left to drain
+    if (!hptr) return SH_OK;
+    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    return hipHostFree(hptr) == hipSuccess ? SH_OK : SH_ERR_HIP;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipHostFree(hptr));

@@ -169,12 +169,15 @@ def emit():
         name = "B2A_COLS" if half == 0 else "B2A_DIAGS"
         body = " \\\n  ".join('"%s\\n"' % l for l in ([".p2align 3"] if ALIGN else []) + half_round(groups))
         out.append("#define %s \\\n  %s" % (name, body))
+    out.append("#ifndef B2A_QUAL")
+    out.append("#define B2A_QUAL  // -DB2A_QUAL=volatile keeps the blocks of independent hashes in program order (experiments)")
+    out.append("#endif")
     out.append("__device__ __forceinline__ void b2_rounds_asm(uint32_t (&v)[16], const uint32_t (&m)[16]) {")
     for r in range(10):
         s = SIGMA[r]
         for half in range(2):
             ms = ", ".join('"v"(m[%d])' % s[8 * half + i] for i in range(8))
-            out.append("  asm(%s : B2A_STATE : %s);" % ("B2A_COLS" if half == 0 else "B2A_DIAGS", ms))
+            out.append("  asm B2A_QUAL(%s : B2A_STATE : %s);" % ("B2A_COLS" if half == 0 else "B2A_DIAGS", ms))
     out.append("}")
     out.append("#undef B2A_STATE")
     out.append("#undef B2A_COLS")

@@ -585,6 +585,8 @@ hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes
   while ((1ull << logn) < n) ++logn;
   int L = (int)logn - 2;
   // wide levels: two levels per launch at full lane efficiency, while a level still fills the chip
+  // (the threshold is flat: 2^15 .. 2^19 threads measure within +-1.5 % of each other on 2^20 .. 2^24 leaves and on the FRI
+  // commits, profiles/r04_merkle_lab.txt)
   while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << 15)) {
     if (((1ull << (L - 2)) * batch) >= MERKLE_WIDE_THREADS / 2)
       hipLaunchKernelGGL(merkle_mid_kernel<true>, dim3(grid_for(1ull << (L - 2)), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);

@@ -1190,3 +1190,26 @@ def test_two_contexts_in_one_process(sa, oracle):
     assert L.sh_dev_to_wire(ctx, dx, host, n) == 0
     assert host.raw == oracle.c.fft_bytes(wire(seeded(9, i) for i in range(n)), n, root_of(n))
     assert L.sh_dev_free(ctx, dx) == 0
+
+
+def test_pinned_buffer_outlives_its_context():
+    """A page-locked buffer belongs to the process: sh_host_free(NULL, ptr) releases it after the allocating context is gone
+    (what PinnedBuffer.close does after _lib.close()), and a double close is harmless."""
+    import ctypes, subprocess, sys
+    from conftest import ROOT
+    code = (
+        "import ctypes\n"
+        "from starks_amd import _lib\n"
+        "L = _lib.lib()\n"
+        "b = _lib.PinnedBuffer(1 << 20)\n"
+        "b.view[:4] = b'abcd'\n"
+        "p = ctypes.c_void_p()\n"
+        "assert L.sh_host_alloc(_lib.ctx(), 4096, ctypes.byref(p)) == 0\n"
+        "_lib.close()\n"
+        "assert L.sh_host_free(None, p) == 0\n"
+        "assert L.sh_host_free(None, None) == 0\n"
+        "b.close(); b.close()\n"
+        "assert b.ptr is None and b.view is None\n"
+        "print('ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -351,3 +351,16 @@ def test_library_plan_queries_from_two_threads():
     [t.join() for t in ts]
     assert all(row == want for g in got for row in g)
     assert L.sh_ntt_path_name() == b"valu"
+
+
+def test_to_wire_accepts_iterators_without_losing_elements():
+    """_lib.to_wire on a generator whose fast path fails part way (a field element after plain ints): the general path must see
+    every value, not the tail the fast path left."""
+    from starks_amd import _lib
+    from starks_amd.modp import IntegersModP
+    F = IntegersModP(P)
+    vals = [1, 2, F(3), -1, 2**256 + 5]
+    want = b"".join((int(v) % P if not 0 <= int(v) < 2**256 else int(v)).to_bytes(32, "big") for v in vals)
+    assert _lib.to_wire(iter(vals)) == want
+    assert _lib.to_wire(v for v in vals) == want
+    assert _lib.to_wire(vals) == want and _lib.to_wire(tuple(vals)) == want
