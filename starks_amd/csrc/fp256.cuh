@@ -259,7 +259,10 @@ FP_HD fp fp_reduce_wide(const uint32_t t[16]) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#include "fp256_mulasm.inc"  // fp_mul_wide_asm: the same product as fp_mul_wide, hand-scheduled for gfx950
+#ifndef FP_MULASM_INC
+#define FP_MULASM_INC "fp256_mulasm.inc"
+#endif
+#include FP_MULASM_INC  // fp_mul_wide_asm: the same product as fp_mul_wide, hand-scheduled for gfx950
 #endif
 
 // (a * b) mod p, lazily reduced.  modp.py:51-53.

@@ -183,8 +183,10 @@ def test_merkle_golden(sa):
             assert [x.hex() for x in sa.mt.mk_branch(t, int(i))] == br
 
 
-@pytest.mark.parametrize("logn", [2, 3, 5, 9, 10, 11, 12, 13, 17, 20])
+@pytest.mark.parametrize("logn", [2, 3, 5, 9, 10, 11, 12, 13, 17, 20, 21, 22])
 def test_merkle_sizes_vs_oracle(sa, oracle, logn):
+    """Every node of the tree against the C oracle.  From 2^21 leaves up the leaf and mid kernels are launched in their WIDE form
+    (asm BLAKE2s rounds, csrc/blake2s.cuh; below that the C++ rounds): both forms are compared with the oracle's hashes."""
     n = 1 << logn
     rng = random.Random(logn)
     leaves = bytes(rng.getrandbits(8) for _ in range(32 * min(n, 4096))) * max(1, n // 4096)
