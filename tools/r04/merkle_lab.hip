@@ -136,6 +136,19 @@ int main() {
   run<13, 4>(dx, dt, n, "no leaf-level store, 16 KiB of LDS");
   run<8, 1>(dx, dt, n, "hashing only (inputs synthesised, nothing stored)");
   run<8, 8>(dx, dt, n, "hashing only, 32 KiB of LDS allocated");
+  run<8, 2>(dx, dt, n, "hashing only (8 KiB: up to 6 waves per SIMD by registers)");
+  run<8, 5>(dx, dt, n, "hashing only (20 KiB: 8 workgroups fit, registers allow 6)");
+  run<8, 6>(dx, dt, n, "hashing only (24 KiB: 6 workgroups per CU)");
+  run<8, 7>(dx, dt, n, "hashing only (28 KiB: 5 workgroups per CU)");
+  run<8, 10>(dx, dt, n, "hashing only (40 KiB: 4 workgroups per CU)");
+  run<8, 12>(dx, dt, n, "hashing only (48 KiB: 3 workgroups per CU)");
+  run<8, 16>(dx, dt, n, "hashing only (64 KiB: 2 workgroups per CU)");
+  run<15, 10>(dx, dt, n, "everything (40 KiB: 4 workgroups per CU)");
+  run<15, 12>(dx, dt, n, "everything (48 KiB: 3 workgroups per CU)");
+  run<15, 8>(dx, dt, n, "everything (32 KiB) again, after the others");
+  run<15, 9>(dx, dt, n, "everything (36 KiB: 4 workgroups per CU)");
+  run<15, 10>(dx, dt, n, "everything (40 KiB: 4 workgroups per CU) again");
+  run<15, 8>(dx, dt, n, "everything (32 KiB) a third time");
   run<9, 1>(dx, dt, n, "loads + hashing, nothing stored");
   run<7, 8>(dx, dt, n, "loads + both stores through LDS, no hashing (memory path alone)");
   run<5, 4>(dx, dt, n, "loads + pair-level store, no hashing");
