@@ -140,36 +140,47 @@ __device__ __forceinline__ void block_load_chunks(uint4* lds, const uint4* gsrc,
 // workgroup barrier is involved and the waves of a workgroup drift apart instead of meeting four times per tile: measured on the
 // leaf kernel without the leaf-level store 409 -> 339 us for 2^24 values (tools/r04/merkle_lab.hip, profiles/r04_merkle_lab.txt).
 // `limit` = valid chunks of the whole block, as above.
+#if defined(SHK_WAVE_SYNC_BLOCK)  // diagnostic builds: a workgroup barrier in its place (every thread of a workgroup reaches every hand-over)
+#define SHK_WAVE_SYNC() __syncthreads()
+#else
 #define SHK_WAVE_SYNC()                                  \
   do {                                                   \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
     __builtin_amdgcn_wave_barrier();                     \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
-template <int CH>
+#endif
+// LDS_CH = the chunks per thread the workgroup's LDS array was sized for: wave w owns the slice [w * 64 * LDS_CH, (w + 1) * 64 * LDS_CH)
+// in EVERY hand-over of the kernel, whatever that hand-over's own CH <= LDS_CH.  (Round 4 found the mid kernel loading through slices
+// of 512 chunks and storing through slices of 256: a wave that was already storing wrote into the slice its neighbour was still loading
+// through -- invisible while the waves of a workgroup run in step, wrong digests as soon as a second stream perturbs them;
+// tools/r04/c5_repro.py, profiles/r04_two_context_race.txt.)
+template <int CH, int LDS_CH = CH>
 __device__ __forceinline__ void wave_store_chunks(uint4* lds, uint4* gdst, const uint4 (&v)[CH], uint32_t t, uint32_t limit) {
-  const uint32_t lane = t & 63u, base = (t >> 6) * (64 * CH);
+  static_assert(CH <= LDS_CH, "a hand-over must fit the wave's own LDS slice");
+  const uint32_t lane = t & 63u, gbase = (t >> 6) * (64 * CH), lbase = (t >> 6) * (64 * LDS_CH);
 #pragma unroll
-  for (int c = 0; c < CH; ++c) lds[base + chunk_swz(CH * lane + c)] = v[c];
+  for (int c = 0; c < CH; ++c) lds[lbase + chunk_swz(CH * lane + c)] = v[c];
   SHK_WAVE_SYNC();
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const uint32_t c = k * 64 + lane;
-    if (base + c < limit) gdst[base + c] = lds[base + chunk_swz(c)];
+    if (gbase + c < limit) gdst[gbase + c] = lds[lbase + chunk_swz(c)];
   }
   SHK_WAVE_SYNC();
 }
-template <int CH>
+template <int CH, int LDS_CH = CH>
 __device__ __forceinline__ void wave_load_chunks(uint4* lds, const uint4* gsrc, uint4 (&v)[CH], uint32_t t, uint32_t limit) {
-  const uint32_t lane = t & 63u, base = (t >> 6) * (64 * CH);
+  static_assert(CH <= LDS_CH, "a hand-over must fit the wave's own LDS slice");
+  const uint32_t lane = t & 63u, gbase = (t >> 6) * (64 * CH), lbase = (t >> 6) * (64 * LDS_CH);
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     const uint32_t c = k * 64 + lane;
-    if (base + c < limit) lds[base + chunk_swz(c)] = gsrc[base + c];
+    if (gbase + c < limit) lds[lbase + chunk_swz(c)] = gsrc[gbase + c];
   }
   SHK_WAVE_SYNC();
 #pragma unroll
-  for (int c = 0; c < CH; ++c) v[c] = lds[base + chunk_swz(CH * lane + c)];
+  for (int c = 0; c < CH; ++c) v[c] = lds[lbase + chunk_swz(CH * lane + c)];
   SHK_WAVE_SYNC();
 }
 __device__ __forceinline__ uint4 pack4(const uint32_t* w) { return make_uint4(w[0], w[1], w[2], w[3]); }
@@ -257,7 +268,7 @@ __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64
   uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
   uint4 v[8];
 #if SHK_MID_WAVE
-  wave_load_chunks<8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
+  wave_load_chunks<8, 8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
 #else
   block_load_chunks<8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
 #endif
@@ -272,7 +283,7 @@ __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64
   {
     uint4 u[4] = {pack4(d0.h), pack4(d0.h + 4), pack4(d1.h), pack4(d1.h + 4)};
 #if SHK_MID_WAVE
-    wave_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
+    wave_store_chunks<4, 8>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
 #else
     block_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
 #endif

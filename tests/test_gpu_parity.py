@@ -1215,3 +1215,68 @@ def test_pinned_buffer_outlives_its_context():
         "print('ok')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+def test_two_contexts_running_at_once_give_the_single_context_bytes(sa):
+    """Two library contexts (two streams) proving / hashing at the same time give, byte for byte, what one context gives alone.
+    Regression test of round 4: the Merkle mid kernel handed its nodes over per wave through LDS slices of two different
+    geometries, so a wave that was ahead wrote into the slice its neighbour was still reading -- invisible while the waves of a
+    workgroup run in step (one stream), 5-30 % wrong proofs as soon as a second stream perturbed them (bench.py deals the batched
+    launches of config 5 to two contexts).  Every proof and every tree is compared, not a sample."""
+    import ctypes
+    from starks_amd import batch
+    L = sa.lib.lib()
+    steps, ext, k = 1 << 13, 8, 64
+    a = batch.StarkUnitProver(steps, ext, chunk=k)
+    b = batch.StarkUnitProver(steps, ext, chunk=k, second_context=True)
+    try:
+        a.generate(0, k)
+        a.prove(k)
+        ref_a = a.download(k)
+        a.generate(k, k)
+        a.prove(k)
+        ref_b = a.download(k)      # units k .. 2k-1 proved on the FIRST context, alone
+        a.generate(0, k)
+        b.generate(k, k)
+        a.status()
+        b.status()
+        bad = 0
+        for _ in range(6):
+            for _ in range(3):     # both streams stay busy: three launch sequences each, interleaved
+                a.prove(k)
+                b.prove(k)
+            got_a, got_b = a.download(k), b.download(k)
+            bad += sum(1 for x, y in zip(ref_a + ref_b, got_a + got_b) if x != y)
+        assert bad == 0, "%d of %d proofs differ between concurrent and single-context runs" % (bad, 6 * 2 * k)
+    finally:
+        a.close()
+        b.close()
+    # the same for a bare Merkle commit wide enough for the mid kernels (2^22 leaves), both contexts hashing different data
+    ctx, other = sa.lib.ctx(), sa.lib.second_ctx()
+    n = 1 << 22
+    bufs = []
+    for c, seed in ((ctx, 11), (other, 12)):
+        dx, dt = ctypes.c_void_p(), ctypes.c_void_p()
+        assert L.sh_dev_alloc(c, 32 * n, ctypes.byref(dx)) == 0 and L.sh_dev_alloc(c, 64 * n, ctypes.byref(dt)) == 0
+        assert L.sh_dev_fill_seeded(c, dx, n, seed) == 0
+        bufs.append((c, dx, dt))
+
+    def tree_digest(c, dt):
+        host = ctypes.create_string_buffer(64 * n)
+        assert L.sh_dev_download(c, dt, host, 64 * n) == 0
+        return hashlib.sha256(host.raw).digest()
+
+    try:
+        alone = []
+        for c, dx, dt in bufs:
+            assert L.sh_dev_merkelize(c, dx, n, 1, dt) == 0
+            alone.append(tree_digest(c, dt))
+        for _ in range(4):
+            for _ in range(8):
+                for c, dx, dt in bufs:
+                    assert L.sh_dev_merkelize(c, dx, n, 1, dt) == 0
+            assert [tree_digest(c, dt) for c, dx, dt in bufs] == alone
+    finally:
+        for c, dx, dt in bufs:
+            L.sh_dev_free(c, dx)
+            L.sh_dev_free(c, dt)
