@@ -402,6 +402,111 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
   fp_store(a.column + b * q + i, fp_mul(acc, a.inv_4));
 }
 
+// ---- the small rounds of a commit in one launch -----------------------------------------------------------------------
+// One workgroup of 1024 threads (256 quads) per proof; per round: fold (the thread also leaves the column value's wire form at its
+// permute4 slot of the column tree's leaf level), then the tree level by level with the quad-lane BLAKE2s: levels wider than 256
+// hashes in passes through global memory, the rest handed up through the quads' LDS message slots as in merkle_top_kernel.
+// The chain is latency all the way (a lone wave issues an instruction every 3-5 ns; a quad-lane compression is ~300 dependent
+// instructions, a fold ~1400), so the launch saves less than the 3-4 launches per round it replaces would suggest: with the
+// rounds up to 2^11 points the 2^14-step commit goes from 0.214 to 0.209 ms (27 -> 19 launches), the larger commits stay level, and
+// taking the 2^13- and 2^15-point rounds too is SLOWER (0.232 / 0.372 ms: one workgroup against the whole chip)
+// (profiles/r04_fri_tail_kernel_ab.txt).
+constexpr int FRI_TAIL_THREADS = 1024, FRI_TAIL_QUADS = FRI_TAIL_THREADS / 4;
+__global__ void __launch_bounds__(FRI_TAIL_THREADS) fri_tail_kernel(FriTailArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t slots[FRI_TAIL_QUADS * 16];
+  const uint32_t tid = threadIdx.x, quad = tid >> 2, ql = tid & 3;
+  const uint64_t b = blockIdx.x;
+  uint32_t* myslot = slots + quad * 16;
+#pragma unroll 1
+  for (uint32_t r = 0; r < a.rounds; ++r) {
+    const FriTailRound& rd = a.r[r];
+    const uint64_t n = rd.n, q = n >> 2, q4 = q >> 2;
+    uint32_t* m2 = rd.nodes_m2 + b * 2 * q * 8;
+    {  // ---- fold (fri_fold_kernel's arithmetic) ----
+      uint32_t sxw[8];
+      load8(rd.nodes_m + (b * 2 * n + 1) * 8, sxw);  // special_x = field(m[1]) (fri.py:229), unreduced bytes
+      const fp sx = fp_from_wire_words(sxw);
+      const uint64_t n0m = (1ull << a.log_n0) - 1;
+#pragma unroll 1
+      for (uint64_t i = tid; i < q; i += FRI_TAIL_THREADS) {
+        const fp* v = rd.values + b * n + i;
+        const fp v0 = fp_load(v), v1 = fp_load(v + q), v2 = fp_load(v + 2 * q), v3 = fp_load(v + 3 * q);
+        const uint64_t e = ((1ull << a.log_n0) - ((i << rd.round_shift) & n0m)) & n0m;
+        fp winv = fp_load(a.tw_lo + (e & ((1ull << a.tw_lb) - 1)));
+        if (a.tw_hi) winv = fp_mul(winv, fp_load(a.tw_hi + (e >> a.tw_lb)));
+        const fp t = fp_mul(sx, winv);
+        const fp u0 = fp_add(v0, v2), u1 = fp_sub(v0, v2), u2 = fp_add(v1, v3);
+        const fp u3 = fp_mul(fp_sub(v1, v3), a.inv_i);
+        const fp G0 = fp_add(u0, u2), G2 = fp_sub(u0, u2), G1 = fp_add(u1, u3), G3 = fp_sub(u1, u3);
+        fp acc = fp_add(fp_mul(G3, t), G2);
+        acc = fp_add(fp_mul(acc, t), G1);
+        acc = fp_add(fp_mul(acc, t), G0);
+        const fp c = fp_mul(acc, a.inv_4);
+        fp_store(rd.column + b * q + i, c);
+        uint32_t w[8];
+        fp_to_wire_words(fp_canon(c), w);
+        store8(m2 + (q + 4 * (i % q4) + i / q4) * 8, w);  // nodes[q + permuted index] (merkle_tree.py:26-33, 47-53)
+      }
+      if (tid == 0) {
+        uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        store8(m2, z);  // nodes[0]: the reference keeps b'' there
+      }
+    }
+    __syncthreads();  // the leaf level is complete (global memory, workgroup scope)
+    // the 40 message-word addresses of the quad-lane hash: derived per round, after the fold (kept live across its 9 products
+    // they would not fit the 128 registers a 1024-thread workgroup leaves a lane)
+    uint32_t slot_base = quad * 64;
+    asm volatile("" : "+v"(slot_base));
+    b2q_addr ad;
+    b2q_addr_init(ad, slot_base, ql);
+    // ---- the column's tree: level lvl = the nodes [2^lvl, 2^(lvl+1)), children of node p at 2p and 2p + 1 ----
+    uint32_t lvl = 0;
+    while ((2ull << lvl) < q) ++lvl;  // log2(q) - 1
+#pragma unroll 1
+    while ((1u << lvl) > (uint32_t)FRI_TAIL_QUADS) {  // wide levels: several passes, children read from global memory
+      const uint32_t mm = 1u << lvl;
+#pragma unroll 1
+      for (uint32_t h = quad; h < mm; h += FRI_TAIL_QUADS) {  // mm is a multiple of the quads: whole waves stay together
+        const uint64_t p = (uint64_t)mm + h;
+        *reinterpret_cast<uint4*>(myslot + 4 * ql) = *reinterpret_cast<const uint4*>(m2 + 2 * p * 8 + 4 * ql);
+        SHK_WAVE_SYNC();  // the slot is this quad's own
+        uint32_t h_lo, h_hi;
+        b2q_compress(ad, slots, ql, 64, h_lo, h_hi);
+        SHK_WAVE_SYNC();
+        m2[p * 8 + ql] = h_lo;
+        m2[p * 8 + 4 + ql] = h_hi;
+      }
+      __syncthreads();
+      --lvl;
+    }
+    uint32_t active = 1u << lvl;  // quads hashing in this step (<= 256)
+    if (quad < active) {
+      const uint64_t p = (uint64_t)active + quad;
+      *reinterpret_cast<uint4*>(myslot + 4 * ql) = *reinterpret_cast<const uint4*>(m2 + 2 * p * 8 + 4 * ql);
+    }
+#pragma unroll 1
+    for (;;) {
+      __syncthreads();  // message slots written
+      uint32_t h_lo = 0, h_hi = 0;
+      if (quad < active) {
+        b2q_compress(ad, slots, ql, 64, h_lo, h_hi);
+        uint32_t* out = m2 + ((uint64_t)active + quad) * 8;
+        out[ql] = h_lo;
+        out[4 + ql] = h_hi;
+      }
+      if (active == 1) break;
+      __syncthreads();  // everyone has read its slot: parents' slots may be overwritten
+      if (quad < active) {
+        uint32_t* dst = slots + (quad >> 1) * 16 + 8 * (quad & 1);
+        dst[ql] = h_lo;
+        dst[4 + ql] = h_hi;
+      }
+      active >>= 1;
+    }
+    __syncthreads();  // the root is in global memory before the next round's fold reads it
+  }
+}
+
 // ---- query sampling + branch gather --------------------------------------------------------------------
 // get_pseudorandom_indices(root, modulus, samples, exclude_multiples_of) (utils.py:60-90): one QUAD of lanes per proof.
 // data = root, then data += blake(data[-32:]) (utils.py:74-75): a serial chain, so each 32-byte block is hashed
@@ -635,6 +740,11 @@ hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st)
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fri_gather_all_kernel, dim3(grid_for(a.work_total)), dim3(TPB), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t shk_fri_tail(const FriTailArgs& a, hipStream_t st) {
+  if (!a.rounds || !a.batch) return hipSuccess;
+  hipLaunchKernelGGL(fri_tail_kernel, dim3(a.batch), dim3(FRI_TAIL_THREADS), 0, st, a);
   return hipGetLastError();
 }
 hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,

@@ -120,7 +120,7 @@ __host__ __device__ constexpr int tile_phase(int g) {
 }
 // row index (with the group's two level bits clear) of the elements of thread tid in group g (not the row pass's group 0)
 template <int LOG_R, int LOG_T, int g>
-__device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
+__host__ __device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
   constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;
   if constexpr (!tile_wave_local<LOG_R, LOG_T>()) {
     const uint32_t rest = tid >> LOG_T;
@@ -147,23 +147,30 @@ __device__ __forceinline__ uint32_t tile_ibase(uint32_t tid) {
   }
 }
 
+// Column t and row base (the group's two level bits clear) of thread tid in group g of a tile pass: its four elements are the rows
+// ibase | (h << beta), h = 0..3, beta = max(LOG_R - 2 (g + 1), 0).  The row pass's first group has its own mapping (lanes run along
+// the contiguous row).  (Also what tests/native/tile_map_host.cpp enumerates on the host to check the wave-local exchanges.)
+template <int LOG_R, int LOG_T, bool LAST, int g>
+__host__ __device__ __forceinline__ void tile_thread_coords(uint32_t tid, uint32_t* t, uint32_t* ibase) {
+  constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;
+  if constexpr (LAST && g == 0) {
+    const uint32_t rest = tid & ((1u << LOG_R) / 4 - 1);
+    *t = tid >> (LOG_R - 2);
+    *ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
+  } else {
+    *t = tid & ((1u << LOG_T) - 1);
+    *ibase = tile_ibase<LOG_R, LOG_T, g>(tid);
+  }
+}
+
 // Register group g: fetch 4 elements (global memory for g == 0, LDS otherwise), do its butterfly levels,
 // and hand the elements to the next group through LDS.
 template <int LOG_R, int LOG_T, bool LAST, int g>
 __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, TileThread& th, uint32_t tid, uint64_t tile0) {
   constexpr int R = 1 << LOG_R;
-  constexpr int T = 1 << LOG_T;
   constexpr int G = (LOG_R + 1) / 2;
   constexpr int beta = (LOG_R - 2 * (g + 1)) > 0 ? (LOG_R - 2 * (g + 1)) : 0;  // position of local bit 0
-  constexpr bool rfast = LAST && g == 0;  // row pass loads: lanes run along the contiguous row
-  if (rfast) {
-    const uint32_t rest = tid & (R / 4 - 1);
-    th.t = tid >> (LOG_R - 2);
-    th.ibase = ((rest >> beta) << (beta + 2)) | (rest & ((1u << beta) - 1u));
-  } else {
-    th.t = tid & (T - 1);
-    th.ibase = tile_ibase<LOG_R, LOG_T, g>(tid);
-  }
+  tile_thread_coords<LOG_R, LOG_T, LAST, g>(tid, &th.t, &th.ibase);
 
   if (g == 0 || (LAST && g == 1)) {
     // (re)derive the global coordinates of this thread's column/row: t changes between the

@@ -1280,3 +1280,70 @@ def test_two_contexts_running_at_once_give_the_single_context_bytes(sa):
         for c, dx, dt in bufs:
             L.sh_dev_free(c, dx)
             L.sh_dev_free(c, dt)
+
+
+def test_parity_holds_beside_a_busy_second_stream(sa, oracle):
+    """The parity checks again while a host thread keeps a SECOND context busy with transforms and Merkle commits: kernels of two
+    streams share the CUs, so the waves of a workgroup no longer run in step -- whatever depends on that timing (round 4: the mid
+    kernel's overlapping per-wave LDS slices) shows here.  Compared: NTT digests of every plan shape against the committed
+    fixtures, Merkle trees of the wide (asm) and narrow kernels against the oracle, the reference's FRI proof of config 3 and its
+    STARK proofs, each several times."""
+    import ctypes, threading
+    L, ctx, other = sa.lib.lib(), sa.lib.ctx(), sa.lib.second_ctx()
+    stop, errors = threading.Event(), []
+
+    def noise():
+        try:
+            n, m = 1 << 20, 1 << 22
+            w = root_of(n).to_bytes(32, "big")
+            dx, dt = ctypes.c_void_p(), ctypes.c_void_p()
+            assert L.sh_dev_alloc(other, 32 * m, ctypes.byref(dx)) == 0 and L.sh_dev_alloc(other, 64 * m, ctypes.byref(dt)) == 0
+            assert L.sh_dev_fill_seeded(other, dx, m, 99) == 0
+            k = 0
+            while not stop.is_set():
+                assert L.sh_dev_ntt(other, dx, dx, n, 4, w, k & 1) == 0
+                assert L.sh_dev_merkelize(other, dx, m >> (k % 3), 1, dt) == 0
+                k += 1
+                if k % 8 == 0:
+                    assert L.sh_sync(other) == 0  # bounded queue depth
+            assert L.sh_sync(other) == 0
+            L.sh_dev_free(other, dx)
+            L.sh_dev_free(other, dt)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    th = threading.Thread(target=noise)
+    th.start()
+    try:
+        for logn in (19, 21, 22, 23):
+            test_ntt_large_digests_vs_oracle_fixture(sa, logn)
+        for rep in range(3):
+            for logn in (13, 20, 22):
+                test_merkle_sizes_vs_oracle(sa, oracle, logn)
+        fri_recs = [r for r in load_golden("fri.json") if r["name"] in ("fri_mimc_2_14",)] or load_golden("fri.json")[-1:]
+        for rep in range(3):
+            for rec in fri_recs:
+                test_fri_proofs_golden(sa, oracle, rec)
+        for c in load_golden("stark.json"):
+            test_stark_proofs_golden(sa, oracle, c)
+        test_fri_batch_and_oracle(sa, oracle)
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("tail_log", ["0", "7", "13", "16"])
+def test_fri_tail_kernel_settings_parity(sa, tail_log):
+    """The one-launch tail of the FRI commit (fri_tail_kernel, knob STARKHIP_FRI_TAIL_LOG; default 11) at other settings -- off, the
+    last rounds only, and far larger than the default (whole small commits inside the one workgroup, wide tree levels in passes) --
+    gives the reference's bytes: the FRI and STARK fixtures, the randomised differentials and the batch tests in a child process."""
+    import subprocess, sys
+    from conftest import ROOT
+    sel = ("test_fri_proofs_golden or test_fri_reference_test_shapes or test_fri_batch_and_oracle or test_randomized_fri_differential or "
+           "test_stark_proofs_golden or test_stark_random_vs_oracle or test_stark_extension_factors_and_tiny_traces or test_degenerate_inputs")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
+                          "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, STARKHIP_FRI_TAIL_LOG=tail_log), cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout

@@ -364,3 +364,18 @@ def test_to_wire_accepts_iterators_without_losing_elements():
     assert _lib.to_wire(iter(vals)) == want
     assert _lib.to_wire(v for v in vals) == want
     assert _lib.to_wire(vals) == want and _lib.to_wire(tuple(vals)) == want
+
+
+def test_ntt_tile_mapping_keeps_barrier_free_exchanges_inside_a_wave(tmp_path):
+    """csrc/ntt_kernels.cuh on the host (tests/native/tile_map_host.cpp, hipcc): for every tile shape the library instantiates, each
+    register group's threads partition the tile, the LDS image is a linear bijection, and wherever two consecutive groups hand their
+    elements over WITHOUT a workgroup barrier the LDS slots a wave reads are exactly the ones the same wave wrote.  (Round 4: a
+    Merkle kernel broke the analogous rule -- two hand-overs with different per-wave slices -- and only showed under a second
+    stream; the Merkle side is a static_assert in kernels.hip and a two-context GPU test.)"""
+    import subprocess
+    exe = tmp_path / "tile_map_host"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "--offload-arch=gfx950", "-std=c++17", "-I", os.path.join(ROOT, "starks_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "native", "tile_map_host.cpp"), "-o", str(exe)], stderr=subprocess.DEVNULL)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip() == "37 tile shapes, 85 barrier-free exchanges, 0 failures"
