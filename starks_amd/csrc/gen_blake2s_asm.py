@@ -17,7 +17,8 @@ Bare pair-hash loop (tools/blake_occ.hip, G hashes/s, 4-8 waves per SIMD):
     lock-step, v_add3, branch after the rotates             48.0-48.3
     lock-step, two adds, branch after the rotates           50.3-51.3      <- emitted by default
     model: 800 fast + 320 slow instructions at 0.9 / 1.72 ns     51.6
---add3 / --e64 / --no-branch / --branch-after=... / --align select the other forms for A/B builds.
+    lock-step, two adds, branches, rotr 16 as two v_xor_b32_sdwa     46.8-47.4      (--sdwa16: the sub-dword forms issue at the slow rate)
+--add3 / --e64 / --no-branch / --branch-after=... / --align / --sdwa16 select the other forms for A/B builds.
 
 Each half-round (4 x G) is one asm block: 16 state registers in/out, 8 message words in (24 operands; inline asm allows 30).
 The blocks are not volatile: the compiler may move whole blocks of two independent hashes past each other, never inside.
@@ -46,6 +47,7 @@ DIAGS = [(0, 5, 10, 15), (1, 6, 11, 12), (2, 7, 8, 13), (3, 4, 9, 14)]
 ADD3 = False   # a = a + b + x as one v_add3_u32 (VOP3) instead of two v_add_u32
 E64 = False    # the VOP2 adds / xors in their 8-byte VOP3 encoding
 ALIGN = False  # every block starts 8-byte aligned (.p2align 3): with four columns per line the 8-byte instructions stay aligned
+SDWA16 = False # d = rotr(d ^ a, 16) as two sub-dword xors into a scratch register (v_xor_b32_sdwa) instead of v_xor_b32 + v_alignbit_b32
 BRANCH = 0     # a taken s_branch to the next instruction after every BRANCH lines of a half-round (0 = none)
 BRANCH_OP = "s_branch 0"
 BRANCH_AFTER = (4, 7, 11, 14)  # a taken s_branch to the next instruction after these lines (1-based) of a half-round: the rotates
@@ -68,13 +70,25 @@ def half_round(groups):
             each("v_add_u32" + sfx + " %{a}, %{a}, %{" + m + "}")
 
     add_ab("x")
-    each("v_xor_b32" + sfx + " %{d}, %{d}, %{a}")
-    each("v_alignbit_b32 %{d}, %{d}, %{d}, 16")
-    each("v_add_u32" + sfx + " %{c}, %{c}, %{d}")
+    if SDWA16:
+        # operands %24..%27: scratch registers t_g; t = rotr(d ^ a, 16) word by word, d comes home with the next xor
+        def each_t(fmt):
+            for g, (a, b, c, d) in enumerate(groups):
+                lines.append(fmt.format(a=a, b=b, c=c, d=d, t=24 + g))
+        each_t("v_xor_b32_sdwa %{t}, %{d}, %{a} dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0")
+        each_t("v_xor_b32_sdwa %{t}, %{d}, %{a} dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1")
+        each_t("v_add_u32" + sfx + " %{c}, %{c}, %{t}")
+    else:
+        each("v_xor_b32" + sfx + " %{d}, %{d}, %{a}")
+        each("v_alignbit_b32 %{d}, %{d}, %{d}, 16")
+        each("v_add_u32" + sfx + " %{c}, %{c}, %{d}")
     each("v_xor_b32" + sfx + " %{b}, %{b}, %{c}")
     each("v_alignbit_b32 %{b}, %{b}, %{b}, 12")
     add_ab("y")
-    each("v_xor_b32" + sfx + " %{d}, %{d}, %{a}")
+    if SDWA16:
+        each_t("v_xor_b32" + sfx + " %{d}, %{t}, %{a}")
+    else:
+        each("v_xor_b32" + sfx + " %{d}, %{d}, %{a}")
     each("v_alignbit_b32 %{d}, %{d}, %{d}, 8")
     each("v_add_u32" + sfx + " %{c}, %{c}, %{d}")
     each("v_xor_b32" + sfx + " %{b}, %{b}, %{c}")
@@ -106,10 +120,19 @@ def simulate(m, v):
     v = list(v)
     for r in range(10):
         for half, groups in enumerate((COLS, DIAGS)):
-            ops = list(v) + [m[SIGMA[r][8 * half + i]] for i in range(8)]
+            ops = list(v) + [m[SIGMA[r][8 * half + i]] for i in range(8)] + [0xDEADBEEF] * 4
             for line in half_round(groups):
                 op, rest = line.split(" ", 1)
                 if op.startswith("s_"):
+                    continue
+                if op == "v_xor_b32_sdwa":
+                    regs, mods = rest.split(" dst_sel:")
+                    dst, s0, s1 = [int(a.strip()[1:]) for a in regs.split(",")]
+                    f = dict(kv.split(":") for kv in ("dst_sel:" + mods).split())
+                    pick = lambda x, sel: (x >> 16) if sel == "WORD_1" else (x & 0xFFFF)
+                    val16 = pick(ops[s0], f["src0_sel"]) ^ pick(ops[s1], f["src1_sel"])
+                    keep = ops[dst] if f["dst_unused"] == "UNUSED_PRESERVE" else 0
+                    ops[dst] = (keep & 0x0000FFFF) | (val16 << 16) if f["dst_sel"] == "WORD_1" else (keep & 0xFFFF0000) | val16
                     continue
                 args = [a.strip() for a in rest.split(",")]
                 val = [ops[int(a[1:])] if a.startswith("%") else int(a) for a in args]
@@ -173,11 +196,20 @@ def emit():
     out.append("#define B2A_QUAL  // -DB2A_QUAL=volatile keeps the blocks of independent hashes in program order (experiments)")
     out.append("#endif")
     out.append("__device__ __forceinline__ void b2_rounds_asm(uint32_t (&v)[16], const uint32_t (&m)[16]) {")
+    if SDWA16:
+        out.append("  uint32_t t0, t1, t2, t3, mm[16];")
+        out.append("  for (int i = 0; i < 16; ++i) mm[i] = m[i];")
     for r in range(10):
         s = SIGMA[r]
         for half in range(2):
             ms = ", ".join('"v"(m[%d])' % s[8 * half + i] for i in range(8))
-            out.append("  asm B2A_QUAL(%s : B2A_STATE : %s);" % ("B2A_COLS" if half == 0 else "B2A_DIAGS", ms))
+            if SDWA16:  # operands: 16 state (+v), then the 4 scratch outputs must be numbered 24..27 -> they come after the inputs in
+                # the text but inline asm numbers outputs first; so the message words are passed as "+v" too (numbers 16..23)
+                ms_io = ", ".join('"+v"(mm[%d])' % s[8 * half + i] for i in range(8))
+                out.append("  asm B2A_QUAL(%s : B2A_STATE, %s, \"=&v\"(t0), \"=&v\"(t1), \"=&v\"(t2), \"=&v\"(t3));" %
+                           ("B2A_COLS" if half == 0 else "B2A_DIAGS", ms_io))
+            else:
+                out.append("  asm B2A_QUAL(%s : B2A_STATE : %s);" % ("B2A_COLS" if half == 0 else "B2A_DIAGS", ms))
     out.append("}")
     out.append("#undef B2A_STATE")
     out.append("#undef B2A_COLS")
@@ -186,7 +218,8 @@ def emit():
 
 
 def main():
-    global ADD3, E64, ALIGN, BRANCH, BRANCH_OP, BRANCH_AFTER
+    global ADD3, E64, ALIGN, BRANCH, BRANCH_OP, BRANCH_AFTER, SDWA16
+    SDWA16 = "--sdwa16" in sys.argv
     import random
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     if "--add3" in sys.argv:
