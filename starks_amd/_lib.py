@@ -85,6 +85,7 @@ def lib():
         "sh_dev_merkelize": (i32, [c_p, c_p, u64, u32, c_p]),
         "sh_dev_fri_fold": (i32, [c_p, c_p, c_p, u64, u32, u8p, c_p]),
         "sh_dev_fri_prove": (i32, [c_p, c_p, u64, u8p, u64, u32, u32, u32, c_p]),
+        "sh_dev_fri_prove_coeffs": (i32, [c_p, c_p, u64, u64, u8p, u64, u32, u32, u32, c_p]),
         "sh_stark_proof_len": (u64, [u64, u32, u32, u32, u32]),
         "sh_stark_prove": (i32, [c_p, u8p, u8p, u64, u32, u32, u8p, u8p, c_p, u32, u32, c_p, u64]),
         "sh_dev_stark_prove": (i32, [c_p, c_p, c_p, u64, u32, u32, u8p, u8p, c_p, u32, u32, c_p]),

@@ -1207,6 +1207,14 @@ int sh_dev_fri_prove(sh_ctx* c, const void* d_coeffs, uint64_t n, const uint8_t 
                  reinterpret_cast<uint8_t*>(d_proof));
 }
 
+int sh_dev_fri_prove_coeffs(sh_ctx* c, const void* d_coeffs, uint64_t n_coeffs, uint64_t n, const uint8_t root[32],
+                            uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t samples, uint32_t batch, void* d_proof) {
+  if (!c || !root || n_coeffs == 0 || n_coeffs > n) return SH_ERR_INVALID;
+  SH_TRY(enter(c));
+  return run_fri(c, reinterpret_cast<const fp*>(d_coeffs), n, root, maxdeg_plus_1, exclude, samples, batch,
+                 reinterpret_cast<uint8_t*>(d_proof), n_coeffs);
+}
+
 // ---- host-buffer API --------------------------------------------------------------------------------
 static int upload_padded(sh_ctx* c, const uint8_t* in, uint64_t n_in, uint64_t n, uint32_t batch, int slot, fp** out) {
   void *w = nullptr, *x = nullptr, *y = nullptr;

@@ -382,6 +382,11 @@ def test_full_size_fri_prove_then_verify(sa, logsteps):
     assert L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, 1, dp) == 0
     flat = ctypes.create_string_buffer(plen)
     assert L.sh_dev_download(ctx, dp, flat, plen) == 0
+    # the same commit from the `steps` coefficients alone (implicit padding: the sparse first pass of the evaluation)
+    short = ctypes.create_string_buffer(plen)
+    assert L.sh_dev_fri_prove_coeffs(ctx, dc, steps, n, w, steps, ext, 40, 1, dp) == 0
+    assert L.sh_dev_download(ctx, dp, short, plen) == 0
+    assert short.raw == flat.raw
     proof = sa.fri.unpack_proof(flat.raw, n, steps, 40)
     # the commitment the verifier starts from: root of the tree over the evaluations
     assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dv)) == 0 and L.sh_dev_alloc(ctx, 64 * n, ctypes.byref(dt)) == 0
@@ -1347,3 +1352,38 @@ def test_fri_tail_kernel_settings_parity(sa, tail_log):
                          env=dict(os.environ, STARKHIP_FRI_TAIL_LOG=tail_log), cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+@pytest.mark.parametrize("n_coeffs,logn,batch", [(256, 11, 3), (100, 11, 2), (1, 6, 1), (64, 6, 2), (4096, 15, 2), (5000, 16, 1)])
+def test_device_fri_commit_from_short_coefficient_vectors(sa, oracle, n_coeffs, logn, batch):
+    """sh_dev_fri_prove_coeffs: [batch][n_coeffs] device-resident coefficients (any count up to n, powers of two or not) stand for
+    their zero-padded extension; the proofs equal the C oracle's on the padded polynomials and sh_dev_fri_prove's on the padded
+    vectors."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << logn
+    g2 = root_of(n)
+    w = g2.to_bytes(32, "big")
+    md = max(32, 1 << (n_coeffs - 1).bit_length()) if n_coeffs * 4 <= n else n // 4
+    md = min(md, n // 2)
+    polys = [[seeded(77 + b, i) for i in range(n_coeffs)] for b in range(batch)]
+    plen = sa.fri.proof_len(n, md, 40)
+    ds, dd, dp = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n_coeffs * batch, ctypes.byref(ds)) == 0
+    assert L.sh_dev_alloc(ctx, 32 * n * batch, ctypes.byref(dd)) == 0 and L.sh_dev_alloc(ctx, plen * batch, ctypes.byref(dp)) == 0
+    assert L.sh_dev_from_wire(ctx, b"".join(wire(p) for p in polys), ds, n_coeffs * batch) == 0
+    assert L.sh_dev_from_wire(ctx, b"".join(wire(p + [0] * (n - n_coeffs)) for p in polys), dd, n * batch) == 0
+    out = []
+    for call in (lambda: L.sh_dev_fri_prove_coeffs(ctx, ds, n_coeffs, n, w, md, 8, 40, batch, dp),
+                 lambda: L.sh_dev_fri_prove(ctx, dd, n, w, md, 8, 40, batch, dp)):
+        assert call() == 0
+        host = ctypes.create_string_buffer(plen * batch)
+        assert L.sh_dev_download(ctx, dp, host, plen * batch) == 0
+        out.append(host.raw)
+    assert out[0] == out[1]
+    for b in range(batch):
+        assert out[0][b * plen:(b + 1) * plen] == oracle.c.fri_prove_flat(wire(polys[b]), g2, md, 8, 40, n=n), b
+    assert L.sh_dev_fri_prove_coeffs(ctx, ds, 0, n, w, md, 8, 40, batch, dp) == -1       # SH_ERR_INVALID
+    assert L.sh_dev_fri_prove_coeffs(ctx, ds, n + 1, n, w, md, 8, 40, batch, dp) == -1
+    for d in (ds, dd, dp):
+        assert L.sh_dev_free(ctx, d) == 0

@@ -14,9 +14,12 @@ for logsteps, batch in cfgs:
     plen = int(L.sh_fri_proof_len(n, steps, 40))
     dc, dp = dev.alloc(32 * n * batch), dev.alloc(plen * batch)
     dev.ck(L.sh_dev_fill_seeded(ctx, dc, n * batch, 0xF51), "fill")
-    z = bytes(32 * (n - steps))
-    for b in range(batch):
-        dev.ck(L.sh_dev_upload(ctx, z, ctypes.c_void_p(dc.value + 32 * (b * n + steps)), len(z)), "upload")
-    ms = dev.timed(lambda: dev.ck(L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, batch, dp), "fri"), 5)
+    if os.environ.get("FRI_PROFILE_DENSE") == "1":  # the explicitly zero-padded vector (sh_dev_fri_prove)
+        z = bytes(32 * (n - steps))
+        for b in range(batch):
+            dev.ck(L.sh_dev_upload(ctx, z, ctypes.c_void_p(dc.value + 32 * (b * n + steps)), len(z)), "upload")
+        ms = dev.timed(lambda: dev.ck(L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, batch, dp), "fri"), 5)
+    else:                                           # [batch][steps] coefficients, implicit padding
+        ms = dev.timed(lambda: dev.ck(L.sh_dev_fri_prove_coeffs(ctx, dc, steps, n, w, steps, ext, 40, batch, dp), "fri"), 5)
     print("steps 2^%d batch %d: %.4f ms per launch, %.4f ms per proof" % (logsteps, batch, ms, ms / batch), flush=True)
     dev.free(dc); dev.free(dp)
