@@ -627,7 +627,6 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   uint64_t nn = n, md = maxdeg_plus_1, off = 0;
   uint32_t round = 0;
   const fp inv_i = h_pow(pl->root, 3 * (n / 4));  // I^-1 = I^3, I = root^(n/4)
-  const fp inv_4 = h_inv(fp_from_u32(4u));
   FriSampleArgs sa;
   memset(&sa, 0, sizeof sa);
   sa.batch = batch;
@@ -646,7 +645,6 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   ta.tw_lb = pl->base.lb;
   ta.log_n0 = (uint32_t)pl->log_n;
   ta.inv_i = inv_i;
-  ta.inv_4 = inv_4;
   const uint64_t tail_max_n = shk_knobs().fri_tail_log ? 1ull << shk_knobs().fri_tail_log : 0;
   while (md > 16) {
     if (round >= SHK_FRI_MAX_ROUNDS) return SH_ERR_UNSUPPORTED;
@@ -674,7 +672,6 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
       fa.log_n0 = (uint32_t)pl->log_n;
       fa.round_shift = 2 * round;
       fa.inv_i = inv_i;
-      fa.inv_4 = inv_4;
       HIP_TRY(c, shk_fri_fold(fa, c->stream));                                   // column, fri.py:235-242
       HIP_TRY(c, shk_merkelize(next, false, nn / 4, batch, tree2, c->stream, false));   // m2, fri.py:243
     }
@@ -1195,7 +1192,6 @@ int sh_dev_fri_fold(sh_ctx* c, const void* d_values, const void* d_nodes, uint64
   fa.log_n0 = (uint32_t)pl->log_n;
   fa.round_shift = 0;
   fa.inv_i = h_pow(pl->root, 3 * (n / 4));
-  fa.inv_4 = h_inv(fp_from_u32(4u));
   HIP_TRY(c, shk_fri_fold(fa, c->stream));
   return SH_OK;
 }
@@ -1439,7 +1435,6 @@ int sh_fri_fold(sh_ctx* c, const uint8_t* values, uint64_t n, const uint8_t root
   fa.tw_lb = pl->base.lb;
   fa.log_n0 = (uint32_t)pl->log_n;
   fa.inv_i = h_pow(pl->root, 3 * (n / 4));
-  fa.inv_4 = h_inv(fp_from_u32(4u));
   HIP_TRY(c, shk_fri_fold(fa, c->stream));
   return download_wire(c, reinterpret_cast<fp*>(col), column, n / 4);
 }

@@ -181,6 +181,27 @@ FP_HD fp fp_canon(const fp& a) {
 
 FP_HD fp fp_neg(const fp& a) { return fp_sub(fp_zero(), a); }
 
+// a / 4 mod p without a product: p == 1 (mod 4), so a + k p with k = (-a) mod 4 is divisible by 4, and (a + k p) >> 2 < 2^256 for
+// any a in [0, 2^256) (a + 3 p < 2^258).  Lazily reduced in and out.  (The FRI fold's final 1/4: ~20 instructions against a
+// general product's ~150.)
+FP_HD fp fp_div4(const fp& a) {
+  const uint32_t k = (0u - a.v[0]) & 3u;
+  uint32_t t[9];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t pi = i == 0 ? FP_P0 : i == 1 ? FP_P1 : FP_PX;
+    acc += (uint64_t)a.v[i] + (uint64_t)k * pi;
+    t[i] = (uint32_t)acc;
+    acc >>= 32;
+  }
+  t[8] = (uint32_t)acc;
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = (t[i] >> 2) | (t[i + 1] << 30);
+  return r;
+}
+
 FP_HD bool fp_eq_canon(const fp& a, const fp& b) {
   uint32_t d = 0;
 #pragma unroll

@@ -73,7 +73,6 @@ struct FoldArgs {
   uint32_t log_n0;
   uint32_t round_shift;    // this round's generator is w0^(2^round_shift)
   fp inv_i;                // (w0^(n0/4))^-1: inverse of the primitive 4th root of unity
-  fp inv_4;                // 4^-1
 };
 hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st);
 // Query sampling + branch gather of ALL rounds of a FRI commit in two launches (fri.py:246-254 per round): every round keeps
@@ -123,7 +122,6 @@ struct FriTailArgs {
   uint32_t tw_lb;
   uint32_t log_n0;
   fp inv_i;
-  fp inv_4;
 };
 hipError_t shk_fri_tail(const FriTailArgs& a, hipStream_t st);
 // ys[b][0..samples) = get_pseudorandom_indices(node 1 of tree b, modulus, samples, exclude) (utils.py:60-90);

@@ -57,6 +57,33 @@ int main() {
       if (memcmp(&a, &b, sizeof a)) ++bad;
     }
   }
+  // fp_div4 (the fold's 1/4 by shifting): 4 * (x / 4) == x for random, unreduced and edge operands, and x / 4 == x * 4^-1
+  {
+    const fp four = fp_from_u32(4u);
+    fp inv4 = fp_one();  // 4^-1 = ((p + 1) / 2)^2: build it as 2^-1 squared, 2^-1 = (p + 1) / 2
+    fp half;
+    {  // (p + 1) >> 1, exactly
+      uint32_t q[8] = {FP_P0 + 1u, FP_P1, FP_PX, FP_PX, FP_PX, FP_PX, FP_PX, FP_PX};
+      for (int i = 0; i < 8; ++i) half.v[i] = (q[i] >> 1) | (i < 7 ? q[i + 1] << 31 : 0u);
+    }
+    inv4 = fp_mul(half, half);
+    const fp chk = fp_canon(fp_mul(inv4, four));
+    if (memcmp(&chk, &(const fp&)fp_one(), sizeof chk)) { printf("4^-1 is wrong\n"); ++bad; }
+    for (int it = 0; it < 200000; ++it) {
+      fp x;
+      for (int i = 0; i < 8; ++i) x.v[i] = rnd();
+      const int m = it % 16;
+      if (m == 1) for (int i = 0; i < 8; ++i) x.v[i] = 0xffffffffu;
+      if (m == 2) x = fp_zero();
+      if (m == 3) { x = fp_zero(); x.v[0] = it & 7; }
+      if (m == 4) { for (int i = 2; i < 8; ++i) x.v[i] = FP_PX; x.v[1] = FP_P1; x.v[0] = (uint32_t)(it & 7); }  // p .. p + 7
+      if (m == 5) { for (int i = 2; i < 8; ++i) x.v[i] = FP_PX; x.v[1] = FP_P1 - 1u; x.v[0] = 0xfffffffcu + (it & 3); }  // just below p
+      if (m == 6) { for (int i = 1; i < 8; ++i) x.v[i] = 0xffffffffu; x.v[0] = 0xfffffffcu + (it & 3); }
+      const fp q = fp_div4(x);
+      const fp back = fp_canon(fp_mul(q, four)), want = fp_canon(x), viamul = fp_canon(fp_mul(x, inv4)), qc = fp_canon(q);
+      if (memcmp(&back, &want, sizeof back) || memcmp(&viamul, &qc, sizeof qc)) ++bad;
+    }
+  }
   printf("%ld products, %ld mismatches\n", n, bad);
   return bad != 0;
 }
