@@ -704,8 +704,10 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   }
   sa.rounds = round;
   HIP_TRY(c, shk_fri_tail(ta, c->stream));
+  sa.final_values = vals;  // fri.py:212-214
+  sa.final_n = nn;
+  sa.final_off = off;
   HIP_TRY(c, shk_fri_sample_and_gather_all(sa, c->stream));
-  HIP_TRY(c, shk_fri_final(vals, nn, batch, d_proof, stride, off, c->stream));  // fri.py:212-214
   return SH_OK;
 }
 

@@ -99,6 +99,11 @@ struct FriSampleArgs {
   uint8_t* proof;            // [batch][proof_stride] device proof buffers
   uint64_t proof_stride;
   uint64_t work_total;
+  // the final layer (fri.py:212-214), written by the same gather launch: canonical wire form of final_values[b][0..final_n) at
+  // proof[b] + final_off
+  const fp* final_values;
+  uint64_t final_n;
+  uint64_t final_off;
 };
 hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st);
 // The small rounds of a commit (domains of at most 2^STARKHIP_FRI_TAIL_LOG points, knobs.hpp; default 2^11) in ONE launch: one workgroup per proof walks the serial
@@ -128,9 +133,6 @@ hipError_t shk_fri_tail(const FriTailArgs& a, hipStream_t st);
 // trees are tree_words u32 apart
 hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint32_t modulus, uint32_t batch,
                               uint32_t samples, uint32_t exclude, uint32_t* d_ys, hipStream_t st);
-// final layer: canonical wire form of values[b][0..n) into proof[b] + off
-hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,
-                         uint64_t off, hipStream_t st);
 
 // ---- stark.hip: constraint / boundary quotients, packed tree, linear combination, spot checks (stark.py:233-279) ----
 constexpr uint32_t SHK_STARK_MAX_WIDTH = 9;  // get_pseudorandom_ks returns None from 10 on (stark.py:106-126)

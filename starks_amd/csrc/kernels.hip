@@ -330,11 +330,14 @@ __global__ void __launch_bounds__(TPB) merkle_packed_leaves_kernel(const uint32_
   }
 }
 
-// Top of the tree, where each level waits for the one below: a workgroup of 64 quads reduces 2^levels (<= 128)
+// Top of the tree, where each level waits for the one below: a workgroup of QUADS quads reduces 2^levels (<= 2 QUADS)
 // adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent,
-// children handed up through the quads' LDS message slots.  ~1 us per level instead of ~3.3 us.
-__global__ void __launch_bounds__(TPB) merkle_top_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t levels) {
-  __shared__ __attribute__((aligned(16))) uint32_t slots[64 * 16];
+// children handed up through the quads' LDS message slots.  ~1.4 us per level instead of ~3.3 us.  QUADS = 64 (7 levels per launch)
+// or 128 (8 levels: the trees whose serial part is 15 levels deep -- 2^17 leaves and every larger tree after its wide levels --
+// take two launches instead of three).
+template <int QUADS>
+__global__ void __launch_bounds__(4 * QUADS) merkle_top_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t levels) {
+  __shared__ __attribute__((aligned(16))) uint32_t slots[QUADS * 16];
   uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
   const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
   b2q_addr ad;
@@ -567,7 +570,15 @@ __global__ void __launch_bounds__(64) fri_sample_all_kernel(FriSampleArgs a) {
 // mk_branch (merkle_tree.py:59-68) for the 5 branches of every sample of every round, written into the flat proofs.
 __global__ void __launch_bounds__(TPB) fri_gather_all_kernel(FriSampleArgs a) {
   const uint64_t g0 = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g0 >= a.work_total) return;
+  if (g0 >= a.work_total) {  // the final layer: [x.to_bytes() for x in values] (fri.py:214)
+    const uint64_t g = g0 - a.work_total;
+    if (g >= a.final_n * a.batch) return;
+    const uint64_t b = g / a.final_n, i = g - b * a.final_n;
+    uint32_t w[8];
+    fp_to_wire_words(fp_canon(fp_load(a.final_values + g)), w);
+    store8(reinterpret_cast<uint32_t*>(a.proof + b * a.proof_stride + a.final_off) + 8 * i, w);
+    return;
+  }
   uint32_t ri = 0;
 #pragma unroll 1
   while (ri + 1 < a.rounds && g0 >= a.r[ri + 1].work_begin) ++ri;
@@ -615,16 +626,6 @@ __global__ void __launch_bounds__(TPB) fri_gather_all_kernel(FriSampleArgs a) {
   }
   store8(out + 8 + ((uint64_t)s * per_sample + slot) * 8, w);
 }
-__global__ void __launch_bounds__(TPB) fri_final_kernel(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof,
-                                                        uint64_t stride, uint64_t off) {
-  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= n * batch) return;
-  const uint64_t b = g / n, i = g - b * n;
-  uint32_t w[8];
-  fp_to_wire_words(fp_canon(fp_load(values + g)), w);  // [x.to_bytes() for x in values] (fri.py:214)
-  store8(reinterpret_cast<uint32_t*>(proof + b * stride + off) + 8 * i, w);
-}
-
 }  // namespace
 
 hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st) {
@@ -712,10 +713,15 @@ hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes
     if (e != hipSuccess) return e;
     L -= 2;
   }
+  // the serial levels: as few launches as 8 levels per launch allow, the levels dealt evenly (15 = 8 + 7, 13 = 7 + 6, 11 = 6 + 5)
   while (L > 0) {
-    const int levels = L > 7 ? 7 : L;
-    hipLaunchKernelGGL(merkle_top_kernel, dim3(1u << (L - levels), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L,
-                       (uint32_t)levels);
+    const int launches = (L + 7) / 8, levels = (L + launches - 1) / launches;
+    if (levels == 8)
+      hipLaunchKernelGGL(merkle_top_kernel<128>, dim3(1u << (L - levels), batch), dim3(512), 0, st, d_nodes, n, (uint32_t)L,
+                         (uint32_t)levels);
+    else
+      hipLaunchKernelGGL(merkle_top_kernel<64>, dim3(1u << (L - levels), batch), dim3(256), 0, st, d_nodes, n, (uint32_t)L,
+                         (uint32_t)levels);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     L -= levels;
@@ -735,21 +741,20 @@ hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint
   return hipGetLastError();
 }
 hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st) {
-  if (!a.rounds || !a.batch) return hipSuccess;
+  if (!a.batch) return hipSuccess;
+  if (!a.rounds) {  // a direct proof (maxdeg_plus_1 <= 16): the final layer is all there is
+    hipLaunchKernelGGL(fri_gather_all_kernel, dim3(grid_for(a.final_n * a.batch)), dim3(TPB), 0, st, a);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(fri_sample_all_kernel, dim3((a.batch + 15) / 16, a.rounds), dim3(64), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(fri_gather_all_kernel, dim3(grid_for(a.work_total)), dim3(TPB), 0, st, a);
+  hipLaunchKernelGGL(fri_gather_all_kernel, dim3(grid_for(a.work_total + a.final_n * a.batch)), dim3(TPB), 0, st, a);
   return hipGetLastError();
 }
 hipError_t shk_fri_tail(const FriTailArgs& a, hipStream_t st) {
   if (!a.rounds || !a.batch) return hipSuccess;
   hipLaunchKernelGGL(fri_tail_kernel, dim3(a.batch), dim3(FRI_TAIL_THREADS), 0, st, a);
-  return hipGetLastError();
-}
-hipError_t shk_fri_final(const fp* values, uint64_t n, uint32_t batch, uint8_t* proof, uint64_t proof_stride,
-                         uint64_t off, hipStream_t st) {
-  hipLaunchKernelGGL(fri_final_kernel, dim3(grid_for(n * batch)), dim3(TPB), 0, st, values, n, batch, proof, proof_stride, off);
   return hipGetLastError();
 }
 
