@@ -10,9 +10,9 @@ f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # the last commit = from the last ntt first pass onwards
 idx = [i for i, r in enumerate(rows) if "ntt_pass_kernel" in r["Kernel_Name"] and "false>" in r["Kernel_Name"]]
-# first pass of the last transform: walk back from the end to the last 'fri_final'
-last_final = max(i for i, r in enumerate(rows) if "fri_final" in r["Kernel_Name"])
-prev_final = max([i for i, r in enumerate(rows[:last_final]) if "fri_final" in r["Kernel_Name"]] or [-1])
+# first pass of the last transform: walk back from the end to the last fri_gather_all (the last kernel of a commit)
+last_final = max(i for i, r in enumerate(rows) if "fri_gather_all" in r["Kernel_Name"])
+prev_final = max([i for i, r in enumerate(rows[:last_final]) if "fri_gather_all" in r["Kernel_Name"]] or [-1])
 seg = rows[prev_final + 1:last_final + 1]
 t0 = int(seg[0]["Start_Timestamp"]); prev_end = t0
 tot_k = 0
