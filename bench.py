@@ -223,8 +223,13 @@ def extras(dev, quick):
     dx, dt = dev.alloc(32 * n), dev.alloc(64 * n)
     dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 7), "fill")
     ms = dev.timed(lambda: dev.ck(L.sh_dev_merkelize(ctx, dx, n, 1, dt), "merkle"), 10)
+    # ten commits back to back is long enough for the chip to leave its boost clock (sustained hashing is power-limited: the leaf
+    # kernel of launches 1-3 takes 370 us, that of launches 5-9 440-490 us, profiles/r04_merkle_launch_series.txt); `ms` is that
+    # sustained figure, `ms_after_idle` one commit after 0.3 s of idling
+    time.sleep(0.3)
+    ms1 = dev.timed(lambda: dev.ck(L.sh_dev_merkelize(ctx, dx, n, 1, dt), "merkle"), 1)
     out["merkelize_2^%d" % logn] = {"ms": round(ms, 4), "leaves_per_s": n / ms * 1e3,
-                                    "algorithmic_GBps": 64.0 * n / ms / 1e6}
+                                    "algorithmic_GBps": 64.0 * n / ms / 1e6, "ms_after_idle": round(ms1, 4)}
     dev.free(dx)
     dev.free(dt)
     # ---- LDE: 2^16-step trace, 8x extension, 4 columns (stark.py:27-36 + 253-256) ---------------------------
