@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
 // hashes in passes through global memory, the rest handed up through the quads' LDS message slots as in merkle_top_kernel.
 // The chain is latency all the way (a lone wave issues an instruction every 3-5 ns; a quad-lane compression is ~300 dependent
 // instructions, a fold ~1400), so the launch saves less than the 3-4 launches per round it replaces would suggest: with the
-// rounds up to 2^11 points the 2^14-step commit goes from 0.214 to 0.209 ms (27 -> 19 launches), the larger commits stay level, and
+// rounds up to 2^11 points the 2^14-step commit goes from 0.214 to 0.209 ms (27 -> 22 launches), the larger commits stay level, and
 // taking the 2^13- and 2^15-point rounds too is SLOWER (0.232 / 0.372 ms: one workgroup against the whole chip)
 // (profiles/r04_fri_tail_kernel_ab.txt).
 constexpr int FRI_TAIL_THREADS = 1024, FRI_TAIL_QUADS = FRI_TAIL_THREADS / 4;
