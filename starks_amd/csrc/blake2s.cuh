@@ -160,18 +160,25 @@ __device__ __forceinline__ uint32_t b2q_sigma(int r, int i) {
   return (uint32_t)(S[r] >> (4 * i)) & 15u;
 }
 
+#if defined(B2Q_NO_ASM)
+#define B2Q_DIAG_SHIFT 0u
+#else
+#define B2Q_DIAG_SHIFT 3u
+#endif
 // slot_base: LDS byte address of this quad's 64-byte message slot
 __device__ __forceinline__ void b2q_addr_init(b2q_addr& t, uint32_t slot_base, uint32_t q) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      // k = 0,1: column step words 2q, 2q+1 ; k = 2,3: diagonal step words 8+2q, 9+2q
+      // k = 0,1: column step words 2q, 2q+1 ; k = 2,3: diagonal step words 8+2g, 9+2g of the diagonal g this lane works on
+      // (B2Q_DIAG_OF_LANE: g = q when the rows b, c, d come to lane q; g = q - 1 when b stays and a, c, d move, b2q_compress)
       const int basei = (k < 2 ? 0 : 8) + (k & 1);
-      uint32_t idx = b2q_sigma(r, basei);  // q = 0
-      idx = q == 1 ? b2q_sigma(r, basei + 2) : idx;
-      idx = q == 2 ? b2q_sigma(r, basei + 4) : idx;
-      idx = q == 3 ? b2q_sigma(r, basei + 6) : idx;
+      const uint32_t g = k < 2 ? q : ((q + B2Q_DIAG_SHIFT) & 3u);
+      uint32_t idx = b2q_sigma(r, basei);  // g = 0
+      idx = g == 1 ? b2q_sigma(r, basei + 2) : idx;
+      idx = g == 2 ? b2q_sigma(r, basei + 4) : idx;
+      idx = g == 3 ? b2q_sigma(r, basei + 6) : idx;
       t.a[4 * r + k] = slot_base + 4 * idx;
     }
   }
@@ -184,6 +191,58 @@ __device__ __forceinline__ void b2q_addr_init(b2q_addr& t, uint32_t slot_base, u
 __device__ __forceinline__ uint32_t b2q_word(const uint32_t* slots, uint32_t byte_off) {
   return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(slots) + byte_off);
 }
+// One half-round (G on this lane's column, or on a diagonal) as ONE asm block of 13 instructions.  Between the column and the diagonal
+// arrangement three of the four rows have to move one, two and three lanes; here row b -- the LAST one a G writes and the first one the
+// next G reads -- is the row that stays, and a, c, d move, each inside the instruction that first reads it (DPP quad_perm on src0, no
+// separate v_mov_b32_dpp): a was written six instructions before its DPP read, d and c likewise, so the "VALU write, then DPP read: two
+// wait states" hazard never arises and no s_nop is needed (the compiler's own form: 20 v_mov_b32_dpp and 55 s_nop per compression).
+// In the diagonal step lane q therefore works on the diagonal of b_q, i.e. diagonal q - 1 (its message words: B2Q_DIAG_SHIFT above), and
+// afterwards holds a of column q - 1, c of column q + 1, d of column q + 2.  0.874 -> 0.62 us per compression for a wave alone on its
+// SIMD (tools/r04/quad_latency.hip), which is what a serial tree level costs.  PA / PC / PD: the lane that lane q takes a / c / d from.
+// (The first half-round has nothing to move and its inputs may have been written by the instruction right before it: plain form.)
+// -DB2Q_NO_ASM keeps the C++ form (A/B builds).
+#if !defined(B2Q_NO_ASM)
+#define B2Q_DPPMOD(P) " quad_perm:" P " row_mask:0xf bank_mask:0xf\n"
+// operands: %0 a, %1 b, %2 c, %3 d (in/out), %4 scratch, %5 mx, %6 my
+#define B2Q_G_TAIL_ASM                  \
+  "v_alignbit_b32 %3, %3, %3, 16\n"    \
+  "v_add_u32 %2, %2, %3\n"             \
+  "v_xor_b32 %1, %1, %2\n"             \
+  "v_alignbit_b32 %1, %1, %1, 12\n"    \
+  "v_add3_u32 %0, %0, %1, %6\n"        \
+  "v_xor_b32 %3, %3, %0\n"             \
+  "v_alignbit_b32 %3, %3, %3, 8\n"     \
+  "v_add_u32 %2, %2, %3\n"             \
+  "v_xor_b32 %1, %1, %2\n"             \
+  "v_alignbit_b32 %1, %1, %1, 7\n"
+#define B2Q_HALF_ASM(PA, PC, PD)                        \
+  "v_add_u32 %4, %1, %5\n"                              \
+  "v_add_u32_dpp %0, %0, %4" B2Q_DPPMOD(PA)             \
+  "v_xor_b32_dpp %3, %3, %0" B2Q_DPPMOD(PD)             \
+  "v_alignbit_b32 %3, %3, %3, 16\n"                     \
+  "v_add_u32_dpp %2, %2, %3" B2Q_DPPMOD(PC)             \
+  "v_xor_b32 %1, %1, %2\n"                              \
+  "v_alignbit_b32 %1, %1, %1, 12\n"                     \
+  "v_add3_u32 %0, %0, %1, %6\n"                         \
+  "v_xor_b32 %3, %3, %0\n"                              \
+  "v_alignbit_b32 %3, %3, %3, 8\n"                      \
+  "v_add_u32 %2, %2, %3\n"                              \
+  "v_xor_b32 %1, %1, %2\n"                              \
+  "v_alignbit_b32 %1, %1, %1, 7\n"
+#define B2Q_HALF(PA, PC, PD, mx, my)                                                                            \
+  do {                                                                                                          \
+    uint32_t tmp_;                                                                                              \
+    asm(B2Q_HALF_ASM(PA, PC, PD) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(tmp_) : "v"(mx), "v"(my));       \
+  } while (0)
+// the same with nothing to move (round 0's column step)
+#define B2Q_HALF_PLAIN(mx, my)                                                                                  \
+  do {                                                                                                          \
+    uint32_t tmp_;                                                                                              \
+    asm("v_add3_u32 %0, %0, %1, %5\n"                                                                           \
+        "v_xor_b32 %3, %3, %0\n" B2Q_G_TAIL_ASM                                                                 \
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(tmp_) : "v"(mx), "v"(my));                                  \
+  } while (0)
+#endif
 __device__ __forceinline__ void b2q_compress(const b2q_addr& t, const uint32_t* slots, uint32_t q, uint32_t tcount,
                                              uint32_t& h_lo, uint32_t& h_hi) {
   const uint32_t iv_lo = q == 0 ? 0x6A09E667u : q == 1 ? 0xBB67AE85u : q == 2 ? 0x3C6EF372u : 0xA54FF53Au;
@@ -192,6 +251,25 @@ __device__ __forceinline__ void b2q_compress(const b2q_addr& t, const uint32_t* 
   const uint32_t h0_hi = iv_hi;
   uint32_t a = h0_lo, b = h0_hi, c = iv_lo;
   uint32_t d = iv_hi ^ (q == 0 ? tcount : q == 2 ? 0xffffffffu : 0u);
+#if !defined(B2Q_NO_ASM)
+  {
+    const uint32_t mx = b2q_word(slots, t.a[0]), my = b2q_word(slots, t.a[1]);
+    B2Q_HALF_PLAIN(mx, my);
+  }
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    if (r) {  // column q: a is in lane q + 1, c in lane q - 1, d in lane q - 2 (where the diagonal step left them)
+      const uint32_t mx = b2q_word(slots, t.a[4 * r + 0]), my = b2q_word(slots, t.a[4 * r + 1]);
+      B2Q_HALF("[1,2,3,0]", "[3,0,1,2]", "[2,3,0,1]", mx, my);
+    }
+    // the diagonal through b_q: a from lane q - 1, c from lane q + 1, d from lane q + 2
+    const uint32_t mx = b2q_word(slots, t.a[4 * r + 2]), my = b2q_word(slots, t.a[4 * r + 3]);
+    B2Q_HALF("[3,0,1,2]", "[1,2,3,0]", "[2,3,0,1]", mx, my);
+  }
+  a = B2Q_DPP(a, 0x39);  // back to columns for the feed-forward: a_q from lane q + 1, c_q from lane q - 1, d_q from lane q - 2
+  c = B2Q_DPP(c, 0x93);
+  d = B2Q_DPP(d, 0x4e);
+#else
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     uint32_t mx = b2q_word(slots, t.a[4 * r + 0]), my = b2q_word(slots, t.a[4 * r + 1]);
@@ -206,6 +284,7 @@ __device__ __forceinline__ void b2q_compress(const b2q_addr& t, const uint32_t* 
     c = B2Q_DPP(c, 0x4e);
     d = B2Q_DPP(d, 0x39);
   }
+#endif
   h_lo = h0_lo ^ a ^ c;
   h_hi = h0_hi ^ b ^ d;
 }
