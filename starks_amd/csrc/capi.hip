@@ -635,46 +635,24 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   sa.proof = d_proof;
   sa.proof_stride = stride;
   uint32_t ys_off = 0;
-  // rounds on domains of at most SHK_FRI_TAIL_MAX_N points: recorded here, run by ONE launch after the loop (a workgroup per proof
-  // walks their serial chain; 3-4 launches per round otherwise, 5-10 us each at these sizes)
-  FriTailArgs ta;
-  memset(&ta, 0, sizeof ta);
-  ta.batch = batch;
-  ta.tw_lo = pl->base.lo;
-  ta.tw_hi = pl->base.hi;
-  ta.tw_lb = pl->base.lb;
-  ta.log_n0 = (uint32_t)pl->log_n;
-  ta.inv_i = inv_i;
-  const uint64_t tail_max_n = shk_knobs().fri_tail_log ? 1ull << shk_knobs().fri_tail_log : 0;
   while (md > 16) {
     if (round >= SHK_FRI_MAX_ROUNDS) return SH_ERR_UNSUPPORTED;
     const uint32_t s = round == 0 ? samples : 40;
     if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream, false));  // m = merkelize(values), fri.py:224
-    if (nn <= tail_max_n) {
-      FriTailRound& tr = ta.r[ta.rounds++];
-      tr.values = vals;
-      tr.column = next;
-      tr.nodes_m = tree;
-      tr.nodes_m2 = tree2;
-      tr.n = nn;
-      tr.round_shift = 2 * round;
-    } else {
-      FoldArgs fa;
-      memset(&fa, 0, sizeof fa);
-      fa.values = vals;
-      fa.nodes = tree;
-      fa.column = next;
-      fa.n = nn;
-      fa.batch = batch;
-      fa.tw_lo = pl->base.lo;
-      fa.tw_hi = pl->base.hi;
-      fa.tw_lb = pl->base.lb;
-      fa.log_n0 = (uint32_t)pl->log_n;
-      fa.round_shift = 2 * round;
-      fa.inv_i = inv_i;
-      HIP_TRY(c, shk_fri_fold(fa, c->stream));                                   // column, fri.py:235-242
-      HIP_TRY(c, shk_merkelize(next, false, nn / 4, batch, tree2, c->stream, false));   // m2, fri.py:243
-    }
+    FoldArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.values = vals;
+    fa.nodes = tree;
+    fa.column = next;
+    fa.n = nn;
+    fa.batch = batch;
+    fa.tw_lo = pl->base.lo;
+    fa.tw_hi = pl->base.hi;
+    fa.tw_lb = pl->base.lb;
+    fa.log_n0 = (uint32_t)pl->log_n;
+    fa.round_shift = 2 * round;
+    fa.inv_i = inv_i;
+    HIP_TRY(c, shk_fri_fold_and_tree(fa, tree2, c->stream));                    // column and m2, fri.py:235-243
     // fri.py:246-254 (the 40 sampled rows and their 5 branches each): recorded, done for all rounds at the end
     const uint64_t lg = (uint64_t)ilog2(nn);
     FriRound& r = sa.r[round];
@@ -703,7 +681,6 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
     ++round;
   }
   sa.rounds = round;
-  HIP_TRY(c, shk_fri_tail(ta, c->stream));
   sa.final_values = vals;  // fri.py:212-214
   sa.final_n = nn;
   sa.final_off = off;

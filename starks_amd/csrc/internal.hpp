@@ -75,6 +75,8 @@ struct FoldArgs {
   fp inv_i;                // (w0^(n0/4))^-1: inverse of the primitive 4th root of unity
 };
 hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st);
+// the fold and the Merkle tree of its column (nodes layout of shk_merkelize without the leaf level): [batch][2 * n/4][8 words]
+hipError_t shk_fri_fold_and_tree(const FoldArgs& a, uint32_t* d_nodes2, hipStream_t st);
 // Query sampling + branch gather of ALL rounds of a FRI commit in two launches (fri.py:246-254 per round): every round keeps
 // its values and its tree until the end of the commit, so nothing on the serial chain tree -> challenge -> fold -> tree waits
 // for the 40 x 5 branch copies of the round before.
@@ -106,29 +108,6 @@ struct FriSampleArgs {
   uint64_t final_off;
 };
 hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st);
-// The small rounds of a commit (domains of at most 2^STARKHIP_FRI_TAIL_LOG points, knobs.hpp; default 2^11) in ONE launch: one workgroup per proof walks the serial
-// chain root -> challenge -> fold -> column -> its whole tree -> next root of all of them (fri.py:224-266); the rounds' columns and
-// trees land in the same arenas as the per-round kernels would leave them (plus the column trees' leaf level, which costs
-// nothing at these sizes), so the sampling + gather pass does not care who produced them.
-struct FriTailRound {
-  const fp* values;        // [batch][n]
-  fp* column;              // [batch][n/4]
-  const uint32_t* nodes_m; // [batch][2n][8]  tree of the values (complete when the kernel starts, or produced by the round before)
-  uint32_t* nodes_m2;      // [batch][2q][8]  tree of the column
-  uint64_t n;
-  uint32_t round_shift;    // this round's generator is w0^(2^round_shift)
-};
-struct FriTailArgs {
-  FriTailRound r[SHK_FRI_MAX_ROUNDS];
-  uint32_t rounds;
-  uint32_t batch;
-  const fp* tw_lo;         // powers of the round-0 generator, as in FoldArgs
-  const fp* tw_hi;
-  uint32_t tw_lb;
-  uint32_t log_n0;
-  fp inv_i;
-};
-hipError_t shk_fri_tail(const FriTailArgs& a, hipStream_t st);
 // ys[b][0..samples) = get_pseudorandom_indices(node 1 of tree b, modulus, samples, exclude) (utils.py:60-90);
 // trees are tree_words u32 apart
 hipError_t shk_sample_indices(const uint32_t* d_nodes, uint64_t tree_words, uint32_t modulus, uint32_t batch,

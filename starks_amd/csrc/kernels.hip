@@ -330,45 +330,6 @@ __global__ void __launch_bounds__(TPB) merkle_packed_leaves_kernel(const uint32_
   }
 }
 
-// Top of the tree, where each level waits for the one below: a workgroup of QUADS quads reduces 2^levels (<= 2 QUADS)
-// adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent,
-// children handed up through the quads' LDS message slots.  ~1.4 us per level instead of ~3.3 us.  QUADS = 64 (7 levels per launch)
-// or 128 (8 levels: the trees whose serial part is 15 levels deep -- 2^17 leaves and every larger tree after its wide levels --
-// take two launches instead of three).
-template <int QUADS>
-__global__ void __launch_bounds__(4 * QUADS) merkle_top_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t levels) {
-  __shared__ __attribute__((aligned(16))) uint32_t slots[QUADS * 16];
-  uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
-  const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
-  b2q_addr ad;
-  b2q_addr_init(ad, quad * 64, q);
-  uint32_t active = 1u << (levels - 1);  // quads hashing in this step
-  if (quad < active) {
-    const uint64_t node = (1ull << L) + ((uint64_t)blockIdx.x << levels) + 2 * quad;
-    const uint4 v = *reinterpret_cast<const uint4*>(tree + node * 8 + 4 * q);  // 16 of the pair's 64 bytes
-    *reinterpret_cast<uint4*>(slots + quad * 16 + 4 * q) = v;
-  }
-  uint32_t lvl = L;
-  for (uint32_t s = 0; s < levels; ++s) {
-    __syncthreads();  // message slots written
-    uint32_t h_lo = 0, h_hi = 0;
-    lvl -= 1;
-    if (quad < active) {
-      b2q_compress(ad, slots, q, 64, h_lo, h_hi);
-      uint32_t* out = tree + ((1ull << lvl) + ((uint64_t)blockIdx.x << (levels - 1 - s)) + quad) * 8;
-      out[q] = h_lo;
-      out[4 + q] = h_hi;
-    }
-    __syncthreads();  // everyone has read its slot: parents' slots may be overwritten
-    if (quad < active) {
-      uint32_t* dst = slots + (quad >> 1) * 16 + 8 * (quad & 1);
-      dst[q] = h_lo;
-      dst[4 + q] = h_hi;
-    }
-    active >>= 1;
-  }
-}
-
 // ---- FRI fold ---------------------------------------------------------------------------------------
 // column[i] = P_i(x*), P_i the cubic through (x_i I^j, v_j), v_j = values[i + j q], x_i = w^i, I = w^q.
 // With g = 1/4 * iDFT_4(v) (w.r.t. I) the cubic is sum_k g_k (x / x_i)^k, so
@@ -376,11 +337,8 @@ __global__ void __launch_bounds__(4 * QUADS) merkle_top_kernel(uint32_t* nodes, 
 //   G0 = u0 + u2, G2 = u0 - u2, G1 = u1 + u3, G3 = u1 - u3,
 //   u0 = v0 + v2, u1 = v0 - v2, u2 = v1 + v3, u3 = (v1 - v3) / I.
 // Residues are unique, so this equals the reference's Lagrange route (poly_utils.py:412-440) bit for bit.
-__global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
+__device__ __forceinline__ fp fri_fold_row(const FoldArgs& a, uint64_t b, uint64_t i) {
   const uint64_t q = a.n >> 2;
-  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= q * a.batch) return;
-  const uint64_t b = g / q, i = g - b * q;
   uint32_t sxw[8];
   if (a.nodes) {
     load8(a.nodes + (b * 2 * a.n + 1) * 8, sxw);  // special_x = field(m[1]) (fri.py:229), unreduced bytes
@@ -402,111 +360,84 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
   fp acc = fp_add(fp_mul(G3, t), G2);
   acc = fp_add(fp_mul(acc, t), G1);
   acc = fp_add(fp_mul(acc, t), G0);
-  fp_store(a.column + b * q + i, fp_div4(acc));  // the 1/4 by shifting (fp256.cuh)
+  return fp_div4(acc);  // the 1/4 by shifting (fp256.cuh)
+}
+__global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
+  const uint64_t q = a.n >> 2;
+  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  if (g >= q * a.batch) return;
+  const uint64_t b = g / q, i = g - b * q;
+  fp_store(a.column + b * q + i, fri_fold_row(a, b, i));
 }
 
-// ---- the small rounds of a commit in one launch -----------------------------------------------------------------------
-// One workgroup of 1024 threads (256 quads) per proof; per round: fold (the thread also leaves the column value's wire form at its
-// permute4 slot of the column tree's leaf level), then the tree level by level with the quad-lane BLAKE2s: levels wider than 256
-// hashes in passes through global memory, the rest handed up through the quads' LDS message slots as in merkle_top_kernel.
-// The chain is latency all the way (a lone wave issues an instruction every 3-5 ns; a quad-lane compression is ~300 dependent
-// instructions, a fold ~1400), so the launch saves less than the 3-4 launches per round it replaces would suggest: with the
-// rounds up to 2^11 points the 2^14-step commit goes from 0.214 to 0.209 ms (27 -> 22 launches), the larger commits stay level, and
-// taking the 2^13- and 2^15-point rounds too is SLOWER (0.232 / 0.372 ms: one workgroup against the whole chip)
-// (profiles/r04_fri_tail_kernel_ab.txt).
-constexpr int FRI_TAIL_THREADS = 1024, FRI_TAIL_QUADS = FRI_TAIL_THREADS / 4;
-__global__ void __launch_bounds__(FRI_TAIL_THREADS) fri_tail_kernel(FriTailArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t slots[FRI_TAIL_QUADS * 16];
-  const uint32_t tid = threadIdx.x, quad = tid >> 2, ql = tid & 3;
-  const uint64_t b = blockIdx.x;
-  uint32_t* myslot = slots + quad * 16;
-#pragma unroll 1
-  for (uint32_t r = 0; r < a.rounds; ++r) {
-    const FriTailRound& rd = a.r[r];
-    const uint64_t n = rd.n, q = n >> 2, q4 = q >> 2;
-    uint32_t* m2 = rd.nodes_m2 + b * 2 * q * 8;
-    {  // ---- fold (fri_fold_kernel's arithmetic) ----
-      uint32_t sxw[8];
-      load8(rd.nodes_m + (b * 2 * n + 1) * 8, sxw);  // special_x = field(m[1]) (fri.py:229), unreduced bytes
-      const fp sx = fp_from_wire_words(sxw);
-      const uint64_t n0m = (1ull << a.log_n0) - 1;
-#pragma unroll 1
-      for (uint64_t i = tid; i < q; i += FRI_TAIL_THREADS) {
-        const fp* v = rd.values + b * n + i;
-        const fp v0 = fp_load(v), v1 = fp_load(v + q), v2 = fp_load(v + 2 * q), v3 = fp_load(v + 3 * q);
-        const uint64_t e = ((1ull << a.log_n0) - ((i << rd.round_shift) & n0m)) & n0m;
-        fp winv = fp_load(a.tw_lo + (e & ((1ull << a.tw_lb) - 1)));
-        if (a.tw_hi) winv = fp_mul(winv, fp_load(a.tw_hi + (e >> a.tw_lb)));
-        const fp t = fp_mul(sx, winv);
-        const fp u0 = fp_add(v0, v2), u1 = fp_sub(v0, v2), u2 = fp_add(v1, v3);
-        const fp u3 = fp_mul(fp_sub(v1, v3), a.inv_i);
-        const fp G0 = fp_add(u0, u2), G2 = fp_sub(u0, u2), G1 = fp_add(u1, u3), G3 = fp_sub(u1, u3);
-        fp acc = fp_add(fp_mul(G3, t), G2);
-        acc = fp_add(fp_mul(acc, t), G1);
-        acc = fp_add(fp_mul(acc, t), G0);
-        const fp c = fp_div4(acc);
-        fp_store(rd.column + b * q + i, c);
+// Top of the tree, where each level waits for the one below: a workgroup of QUADS quads reduces 2^levels (<= 2 QUADS)
+// adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent,
+// children handed up through the quads' LDS message slots.  ~1.4 us per level instead of ~3.3 us.  QUADS = 64 (7 levels per launch)
+// or 128 (8 levels: the trees whose serial part is 15 levels deep -- 2^17 leaves and every larger tree after its wide levels --
+// take two launches instead of three).
+// FROM_VALUES: the 2^levels nodes are LEAVES (L = log2 n), derived from the value array [batch][n] (limb form: canonical, big-endian,
+// permute4 order -- the internal trees do not store their leaf level): the whole bottom of a small tree in the same serial form, one
+// launch instead of the leaf kernel (three levels of lane-per-hash compressions, 2.3 us each for a wave that is alone on its SIMD) and
+// a first top launch.
+// LEAVES_FOLD: the values are not there yet: they are THIS round's FRI column, folded here from the previous round's values (one row
+// per leaf, FoldArgs; written to fa.column on the way): the fold launch of a small round disappears into the tree's first launch.
+enum { TOP_FROM_NODES = 0, TOP_FROM_VALUES = 1, TOP_FROM_FOLD = 2 };
+template <int QUADS, int LEAVES = TOP_FROM_NODES>
+__global__ void __launch_bounds__(4 * QUADS) merkle_top_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t levels,
+                                                               const fp* values, FoldArgs fa) {
+  constexpr bool FROM_VALUES = LEAVES != TOP_FROM_NODES;
+  __shared__ __attribute__((aligned(16))) uint32_t slots[QUADS * 16];
+  uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
+  const uint32_t tid = threadIdx.x, quad = tid >> 2, q = tid & 3;
+  b2q_addr ad;
+  b2q_addr_init(ad, quad * 64, q);
+  uint32_t active = 1u << (levels - 1);  // quads hashing in this step
+  if (quad < active) {
+    const uint64_t node = (1ull << L) + ((uint64_t)blockIdx.x << levels) + 2 * quad;
+    if (FROM_VALUES) {
+      if ((q & 1u) == 0) {  // lanes 0 and 2 of the quad fetch the pair's two leaves: slot s holds the value at (s & 3) n/4 + (s >> 2)
+        const uint64_t sl = node - n + (q >> 1), n4 = n >> 2;
         uint32_t w[8];
-        fp_to_wire_words(fp_canon(c), w);
-        store8(m2 + (q + 4 * (i % q4) + i / q4) * 8, w);  // nodes[q + permuted index] (merkle_tree.py:26-33, 47-53)
+        const uint64_t idx = (sl & 3) * n4 + (sl >> 2);
+        fp leaf;
+        if (LEAVES == TOP_FROM_FOLD) {
+          leaf = fri_fold_row(fa, blockIdx.y, idx);
+          fp_store(fa.column + (uint64_t)blockIdx.y * n + idx, leaf);
+        } else {
+          leaf = fp_load(values + (uint64_t)blockIdx.y * n + idx);
+        }
+        fp_to_wire_words(fp_canon(leaf), w);
+        uint4* dst = reinterpret_cast<uint4*>(slots + quad * 16 + 8 * (q >> 1));
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
       }
-      if (tid == 0) {
+      if (blockIdx.x == 0 && tid == 0) {
         uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        store8(m2, z);  // nodes[0]: the reference keeps b'' there
+        store8(tree, z);  // nodes[0]: the reference keeps b'' there
       }
+    } else {
+      const uint4 v = *reinterpret_cast<const uint4*>(tree + node * 8 + 4 * q);  // 16 of the pair's 64 bytes
+      *reinterpret_cast<uint4*>(slots + quad * 16 + 4 * q) = v;
     }
-    __syncthreads();  // the leaf level is complete (global memory, workgroup scope)
-    // the 40 message-word addresses of the quad-lane hash: derived per round, after the fold (kept live across its 9 products
-    // they would not fit the 128 registers a 1024-thread workgroup leaves a lane)
-    uint32_t slot_base = quad * 64;
-    asm volatile("" : "+v"(slot_base));
-    b2q_addr ad;
-    b2q_addr_init(ad, slot_base, ql);
-    // ---- the column's tree: level lvl = the nodes [2^lvl, 2^(lvl+1)), children of node p at 2p and 2p + 1 ----
-    uint32_t lvl = 0;
-    while ((2ull << lvl) < q) ++lvl;  // log2(q) - 1
-#pragma unroll 1
-    while ((1u << lvl) > (uint32_t)FRI_TAIL_QUADS) {  // wide levels: several passes, children read from global memory
-      const uint32_t mm = 1u << lvl;
-#pragma unroll 1
-      for (uint32_t h = quad; h < mm; h += FRI_TAIL_QUADS) {  // mm is a multiple of the quads: whole waves stay together
-        const uint64_t p = (uint64_t)mm + h;
-        *reinterpret_cast<uint4*>(myslot + 4 * ql) = *reinterpret_cast<const uint4*>(m2 + 2 * p * 8 + 4 * ql);
-        SHK_WAVE_SYNC();  // the slot is this quad's own
-        uint32_t h_lo, h_hi;
-        b2q_compress(ad, slots, ql, 64, h_lo, h_hi);
-        SHK_WAVE_SYNC();
-        m2[p * 8 + ql] = h_lo;
-        m2[p * 8 + 4 + ql] = h_hi;
-      }
-      __syncthreads();
-      --lvl;
-    }
-    uint32_t active = 1u << lvl;  // quads hashing in this step (<= 256)
+  }
+  uint32_t lvl = L;
+  for (uint32_t s = 0; s < levels; ++s) {
+    __syncthreads();  // message slots written
+    uint32_t h_lo = 0, h_hi = 0;
+    lvl -= 1;
     if (quad < active) {
-      const uint64_t p = (uint64_t)active + quad;
-      *reinterpret_cast<uint4*>(myslot + 4 * ql) = *reinterpret_cast<const uint4*>(m2 + 2 * p * 8 + 4 * ql);
+      b2q_compress(ad, slots, q, 64, h_lo, h_hi);
+      uint32_t* out = tree + ((1ull << lvl) + ((uint64_t)blockIdx.x << (levels - 1 - s)) + quad) * 8;
+      out[q] = h_lo;
+      out[4 + q] = h_hi;
     }
-#pragma unroll 1
-    for (;;) {
-      __syncthreads();  // message slots written
-      uint32_t h_lo = 0, h_hi = 0;
-      if (quad < active) {
-        b2q_compress(ad, slots, ql, 64, h_lo, h_hi);
-        uint32_t* out = m2 + ((uint64_t)active + quad) * 8;
-        out[ql] = h_lo;
-        out[4 + ql] = h_hi;
-      }
-      if (active == 1) break;
-      __syncthreads();  // everyone has read its slot: parents' slots may be overwritten
-      if (quad < active) {
-        uint32_t* dst = slots + (quad >> 1) * 16 + 8 * (quad & 1);
-        dst[ql] = h_lo;
-        dst[4 + ql] = h_hi;
-      }
-      active >>= 1;
+    __syncthreads();  // everyone has read its slot: parents' slots may be overwritten
+    if (quad < active) {
+      uint32_t* dst = slots + (quad >> 1) * 16 + 8 * (quad & 1);
+      dst[q] = h_lo;
+      dst[4 + q] = h_hi;
     }
-    __syncthreads();  // the root is in global memory before the next round's fold reads it
+    active >>= 1;
   }
 }
 
@@ -672,9 +603,45 @@ hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint3
   hipLaunchKernelGGL(pad_copy_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, src, dst, n_in, n, total);
   return hipGetLastError();
 }
+// the serial levels L .. 1 -> 0 of a tree: as few launches as 8 levels per launch allow, the levels dealt evenly
+// (15 = 8 + 7, 13 = 7 + 6, 11 = 6 + 5)
+#ifndef SHK_SERIAL_TREE_LOG
+#define SHK_SERIAL_TREE_LOG 15
+#endif
+constexpr uint64_t MERKLE_SERIAL_MAX_LEAVES = 1ull << SHK_SERIAL_TREE_LOG;  // trees (times batch) up to this many leaves start in serial form
+static hipError_t merkle_serial_levels(int L, uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st) {
+  while (L > 0) {
+    const int launches = (L + 7) / 8, levels = (L + launches - 1) / launches;
+    if (levels == 8)
+      hipLaunchKernelGGL((merkle_top_kernel<128, TOP_FROM_NODES>), dim3(1u << (L - levels), batch), dim3(512), 0, st, d_nodes, n, (uint32_t)L,
+                         (uint32_t)levels, (const fp*)nullptr, FoldArgs{});
+    else
+      hipLaunchKernelGGL((merkle_top_kernel<64, TOP_FROM_NODES>), dim3(1u << (L - levels), batch), dim3(256), 0, st, d_nodes, n, (uint32_t)L,
+                         (uint32_t)levels, (const fp*)nullptr, FoldArgs{});
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    L -= levels;
+  }
+  return hipSuccess;
+}
 hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint32_t batch, uint32_t* d_nodes,
                          hipStream_t st, bool store_leaves) {
   if (n < 4 || (n & (n - 1)) || batch == 0) return hipErrorInvalidValue;
+  // small trees without a stored leaf level (the later FRI rounds): serial from the leaves up, 8 levels per launch
+  if (!raw_leaves && !store_leaves && n * batch <= MERKLE_SERIAL_MAX_LEAVES) {
+    uint32_t logn = 0;
+    while ((1ull << logn) < n) ++logn;
+    const int launches = ((int)logn + 7) / 8, levels = ((int)logn + launches - 1) / launches;
+    if (levels == 8)
+      hipLaunchKernelGGL((merkle_top_kernel<128, TOP_FROM_VALUES>), dim3(1u << (logn - levels), batch), dim3(512), 0, st, d_nodes, n, logn,
+                         (uint32_t)levels, reinterpret_cast<const fp*>(d_leaves), FoldArgs{});
+    else
+      hipLaunchKernelGGL((merkle_top_kernel<64, TOP_FROM_VALUES>), dim3(1u << (logn - levels), batch), dim3(256), 0, st, d_nodes, n, logn,
+                         (uint32_t)levels, reinterpret_cast<const fp*>(d_leaves), FoldArgs{});
+    const hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return e0;
+    return merkle_serial_levels((int)logn - levels, n, batch, d_nodes, st);
+  }
   const dim3 lgrid(grid_for(n >> 2, TPB * MERKLE_ROWS), batch);
   const bool wide = (n >> 2) * batch >= MERKLE_WIDE_THREADS;
 #define SHK_LEAVES(RAW, STORE)                                                                                           \
@@ -713,20 +680,28 @@ hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes
     if (e != hipSuccess) return e;
     L -= 2;
   }
-  // the serial levels: as few launches as 8 levels per launch allow, the levels dealt evenly (15 = 8 + 7, 13 = 7 + 6, 11 = 6 + 5)
-  while (L > 0) {
-    const int launches = (L + 7) / 8, levels = (L + launches - 1) / launches;
-    if (levels == 8)
-      hipLaunchKernelGGL(merkle_top_kernel<128>, dim3(1u << (L - levels), batch), dim3(512), 0, st, d_nodes, n, (uint32_t)L,
-                         (uint32_t)levels);
-    else
-      hipLaunchKernelGGL(merkle_top_kernel<64>, dim3(1u << (L - levels), batch), dim3(256), 0, st, d_nodes, n, (uint32_t)L,
-                         (uint32_t)levels);
-    e = hipGetLastError();
+  return merkle_serial_levels(L, n, batch, d_nodes, st);
+}
+// column = fold(values) and the whole tree of the column (fri.py:235-243): small rounds fold inside the first launch of the tree
+hipError_t shk_fri_fold_and_tree(const FoldArgs& a, uint32_t* d_nodes2, hipStream_t st) {
+  const uint64_t q = a.n >> 2;
+  if (q < 4 || q * a.batch > MERKLE_SERIAL_MAX_LEAVES) {
+    hipError_t e = shk_fri_fold(a, st);
     if (e != hipSuccess) return e;
-    L -= levels;
+    return shk_merkelize(a.column, false, q, a.batch, d_nodes2, st, false);
   }
-  return hipSuccess;
+  uint32_t logq = 0;
+  while ((1ull << logq) < q) ++logq;
+  const int launches = ((int)logq + 7) / 8, levels = ((int)logq + launches - 1) / launches;
+  if (levels == 8)
+    hipLaunchKernelGGL((merkle_top_kernel<128, TOP_FROM_FOLD>), dim3(1u << (logq - levels), a.batch), dim3(512), 0, st, d_nodes2, q, logq,
+                       (uint32_t)levels, (const fp*)nullptr, a);
+  else
+    hipLaunchKernelGGL((merkle_top_kernel<64, TOP_FROM_FOLD>), dim3(1u << (logq - levels), a.batch), dim3(256), 0, st, d_nodes2, q, logq,
+                       (uint32_t)levels, (const fp*)nullptr, a);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return merkle_serial_levels((int)logq - levels, q, a.batch, d_nodes2, st);
 }
 hipError_t shk_fri_fold(const FoldArgs& a, hipStream_t st) {
   const uint64_t work = (a.n >> 2) * a.batch;
@@ -752,12 +727,6 @@ hipError_t shk_fri_sample_and_gather_all(const FriSampleArgs& a, hipStream_t st)
   hipLaunchKernelGGL(fri_gather_all_kernel, dim3(grid_for(a.work_total + a.final_n * a.batch)), dim3(TPB), 0, st, a);
   return hipGetLastError();
 }
-hipError_t shk_fri_tail(const FriTailArgs& a, hipStream_t st) {
-  if (!a.rounds || !a.batch) return hipSuccess;
-  hipLaunchKernelGGL(fri_tail_kernel, dim3(a.batch), dim3(FRI_TAIL_THREADS), 0, st, a);
-  return hipGetLastError();
-}
-
 hipError_t shk_merkelize_packed(const uint8_t* d_evals, uint64_t n, uint32_t k, uint8_t* d_leaves, uint32_t* d_nodes,
                                 hipStream_t st) {
   if (n < 4 || (n & (n - 1)) || k == 0) return hipErrorInvalidValue;

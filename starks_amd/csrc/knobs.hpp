@@ -14,9 +14,6 @@
 //   STARKHIP_XCD_SWZ=0|1|2|3       workgroup -> tile mapping over the 8 XCDs (ntt_kernels.cuh:shk_launch_tile_kernel)
 //   STARKHIP_TW2_MAX_LOG=k         row-major inter-pass twiddle tables up to 2^k entries (default 24), else the power-table lookup
 //   STARKHIP_PLAN_CACHE_MB=m       initial plan-cache budget of a context
-//   STARKHIP_FRI_TAIL_LOG=k        FRI rounds on domains of at most 2^k points run in the one-launch tail kernel (default 11:
-//                                  measured 2-3 % on the 2^14-step commit, level elsewhere; 13 and 15 are slower,
-//                                  profiles/r04_fri_tail_kernel_ab.txt; 0 = every round through the per-round kernels; 4..16)
 // All of them exist for the parity tests over alternate plans (tests/test_gpu_parity.py::test_alternate_ntt_plans_parity,
 // tools/stress_plans.py) and for A/B measurements; the defaults are the measured best.
 #pragma once
@@ -35,7 +32,6 @@ struct ShkKnobs {
   int n_radices = 0;         // 0: not given (or malformed)
   int radices[4] = {0, 0, 0, 0};
   int radix_sum = 0;
-  int fri_tail_log = 11;     // 0: no tail kernel
 };
 
 namespace shk_knobs_detail {
@@ -71,10 +67,6 @@ inline void parse(ShkKnobs* k) {
   if (const char* e = getenv("STARKHIP_PLAN_CACHE_MB")) {
     const long v = atol(e);
     if (v >= 0) k->plan_cache_mb = v;
-  }
-  if (const char* e = getenv("STARKHIP_FRI_TAIL_LOG")) {
-    const int v = atoi(e);
-    k->fri_tail_log = (v >= 4 && v <= 16) ? v : 0;
   }
   if (const char* e = getenv("STARKHIP_NTT_RADICES")) {
     int r[4] = {0, 0, 0, 0}, cnt = 0, sum = 0;

@@ -1338,22 +1338,6 @@ def test_parity_holds_beside_a_busy_second_stream(sa, oracle):
     assert not errors, errors
 
 
-@pytest.mark.parametrize("tail_log", ["0", "7", "13", "16"])
-def test_fri_tail_kernel_settings_parity(sa, tail_log):
-    """The one-launch tail of the FRI commit (fri_tail_kernel, knob STARKHIP_FRI_TAIL_LOG; default 11) at other settings -- off, the
-    last rounds only, and far larger than the default (whole small commits inside the one workgroup, wide tree levels in passes) --
-    gives the reference's bytes: the FRI and STARK fixtures, the randomised differentials and the batch tests in a child process."""
-    import subprocess, sys
-    from conftest import ROOT
-    sel = ("test_fri_proofs_golden or test_fri_reference_test_shapes or test_fri_batch_and_oracle or test_randomized_fri_differential or "
-           "test_stark_proofs_golden or test_stark_random_vs_oracle or test_stark_extension_factors_and_tiny_traces or test_degenerate_inputs")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m",
-                          "gpu", "-k", sel, "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=600,
-                         env=dict(os.environ, STARKHIP_FRI_TAIL_LOG=tail_log), cwd=ROOT)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert " passed" in out.stdout
-
-
 @pytest.mark.parametrize("n_coeffs,logn,batch", [(256, 11, 3), (100, 11, 2), (1, 6, 1), (64, 6, 2), (4096, 15, 2), (5000, 16, 1)])
 def test_device_fri_commit_from_short_coefficient_vectors(sa, oracle, n_coeffs, logn, batch):
     """sh_dev_fri_prove_coeffs: [batch][n_coeffs] device-resident coefficients (any count up to n, powers of two or not) stand for
