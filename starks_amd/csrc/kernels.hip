@@ -370,17 +370,17 @@ __global__ void __launch_bounds__(TPB) fri_fold_kernel(FoldArgs a) {
   fp_store(a.column + b * q + i, fri_fold_row(a, b, i));
 }
 
-// Top of the tree, where each level waits for the one below: a workgroup of QUADS quads reduces 2^levels (<= 2 QUADS)
-// adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent,
-// children handed up through the quads' LDS message slots.  ~1.4 us per level instead of ~3.3 us.  QUADS = 64 (7 levels per launch)
-// or 128 (8 levels: the trees whose serial part is 15 levels deep -- 2^17 leaves and every larger tree after its wide levels --
-// take two launches instead of three).
-// FROM_VALUES: the 2^levels nodes are LEAVES (L = log2 n), derived from the value array [batch][n] (limb form: canonical, big-endian,
-// permute4 order -- the internal trees do not store their leaf level): the whole bottom of a small tree in the same serial form, one
-// launch instead of the leaf kernel (three levels of lane-per-hash compressions, 2.3 us each for a wave that is alone on its SIMD) and
-// a first top launch.
-// LEAVES_FOLD: the values are not there yet: they are THIS round's FRI column, folded here from the previous round's values (one row
-// per leaf, FoldArgs; written to fa.column on the way): the fold launch of a small round disappears into the tree's first launch.
+// The serial part of a tree, where each level waits for the one below: a workgroup of QUADS quads reduces 2^levels (<= 2 QUADS)
+// adjacent nodes of level L to one node of level L - levels, one quad-lane BLAKE2s (blake2s.cuh) per parent, children handed up
+// through the quads' LDS message slots: ~0.8 us per level (the compression's own chain is 0.64 us) against 2.3 us for a
+// lane-per-hash compression by a wave that is alone on its SIMD.  QUADS = 64 (7 levels per launch) or 128 (8 levels: a 15-level
+// serial part takes two launches instead of three).
+// LEAVES = TOP_FROM_VALUES: the 2^levels nodes are LEAVES (L = log2 n), derived from the value array [batch][n] (limb form ->
+// canonical, big-endian, permute4 order; the internal trees do not store their leaf level): the whole bottom of a small tree in the
+// serial form, one launch instead of the leaf kernel (three levels of lane-per-hash compressions) and a first top launch.
+// LEAVES = TOP_FROM_FOLD: the values are not there yet -- they are THIS round's FRI column, folded here from the previous round's
+// values (one row per leaf, FoldArgs; written to fa.column on the way): the fold launch of a small round disappears into the first
+// launch of its column's tree.  (profiles/r04_serial_small_trees_ab.txt)
 enum { TOP_FROM_NODES = 0, TOP_FROM_VALUES = 1, TOP_FROM_FOLD = 2 };
 template <int QUADS, int LEAVES = TOP_FROM_NODES>
 __global__ void __launch_bounds__(4 * QUADS) merkle_top_kernel(uint32_t* nodes, uint64_t n, uint32_t L, uint32_t levels,
