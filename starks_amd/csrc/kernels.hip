@@ -663,6 +663,9 @@ hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint
   return shk_merkle_upper_levels(n, batch, d_nodes, st);
 }
 // levels log2(n)-2 .. 0 from the nodes the leaf kernels wrote (node layout of merkle_tree.py:36-56)
+#ifndef SHK_MID_MIN_LOG
+#define SHK_MID_MIN_LOG 15  // a level pair goes to the (throughput-form) mid kernel while it has at least 2^this threads
+#endif
 hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st) {
   hipError_t e = hipSuccess;
   uint32_t logn = 0;
@@ -671,7 +674,7 @@ hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes
   // wide levels: two levels per launch at full lane efficiency, while a level still fills the chip
   // (the threshold is flat: 2^15 .. 2^19 threads measure within +-1.5 % of each other on 2^20 .. 2^24 leaves and on the FRI
   // commits, profiles/r04_merkle_lab.txt)
-  while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << 15)) {
+  while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << SHK_MID_MIN_LOG)) {
     if (((1ull << (L - 2)) * batch) >= MERKLE_WIDE_THREADS / 2)
       hipLaunchKernelGGL(merkle_mid_kernel<true>, dim3(grid_for(1ull << (L - 2)), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
     else
