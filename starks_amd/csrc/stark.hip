@@ -196,6 +196,10 @@ __device__ __forceinline__ void leaf_elem(const StarkArgs& a, uint64_t b, uint32
 }
 // One thread per permute4 row: hashes the two leaf pairs (k = 3W BLAKE2s blocks each) and their parent.
 // nodes: [batch][2n] x 32 B (only [0, n) is written: the leaves stay in the evaluation arrays).
+// WIDE: the launch fills the chip several times over and the hashes use the asm rounds (blake2s.cuh); a narrow launch (one small proof),
+// where a wave per SIMD walks its 6 W + 1 compressions alone, keeps the C++ rounds (2.3 against ~4.5 us per compression there).
+constexpr uint64_t STARK_WIDE_THREADS = 1ull << 19;
+template <bool WIDE>
 __global__ void __launch_bounds__(TPB) stark_leaves_kernel(StarkArgs a, uint32_t* nodes) {
   const uint64_t n = a.n, q = n >> 2;
   const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
@@ -215,11 +219,11 @@ __global__ void __launch_bounds__(TPB) stark_leaves_kernel(StarkArgs a, uint32_t
         const uint32_t e = 2 * blk + half;  // element index inside leafA || leafB
         leaf_elem(a, b, e < k ? e : e - k, e < k ? la : lb, m + 8 * half);
       }
-      b2_compress(d[s].h, m, 64 * (blk + 1), blk + 1 == k);
+      b2_compress<WIDE>(d[s].h, m, 64 * (blk + 1), blk + 1 == k);
     }
     store8(tree + (n / 2 + 2 * i + s) * 8, d[s].h);
   }
-  b2digest top = b2_hash_pair(d[0].h, d[1].h);
+  b2digest top = b2_hash_pair<WIDE>(d[0].h, d[1].h);
   store8(tree + (n / 4 + i) * 8, top.h);
   if (i == 0) {
     uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(64) stark_scalars_kernel(const uint32_t* mnode
 // stores the four values and hashes them on the spot -- the tree's leaf pass no longer reads l back, and its hashing runs in
 // the shadow of this kernel's memory traffic (the combination alone is HBM-bound).  nodes: [batch][2n] x 32 B as in
 // kernels.hip (the leaf level itself is not materialised: the branch gather re-derives leaves from l).
-template <int W>  // W = the width when it is 1 or 2 (all values of a point are requested before the first product), else 0
+template <int W, bool WIDE>  // W = the width when it is 1 or 2 (all values of a point are requested before the first product), else 0
 __global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, const fp* scal, fp* l_evals, uint32_t* nodes) {
   // the proof's 3 * width scalar pairs, staged in LDS once per workgroup (kept in registers they would cost 16 VGPRs each)
   // the 3 * width scalars as fp_mul2 pairs: 12 uint4 per trace column, one per thread of the first width * 12
@@ -325,11 +329,11 @@ __global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, 
     fp_store(l_evals + b * N + x, acc);
     fp_to_wire_words(fp_canon(acc), w[r]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
   }
-  const b2digest d0 = b2_hash_pair(w[0], w[1]);
-  const b2digest d1 = b2_hash_pair(w[2], w[3]);
+  const b2digest d0 = b2_hash_pair<WIDE>(w[0], w[1]);
+  const b2digest d1 = b2_hash_pair<WIDE>(w[2], w[3]);
   store8(tree + (N / 2 + 2 * i) * 8, d0.h);
   store8(tree + (N / 2 + 2 * i + 1) * 8, d1.h);
-  const b2digest d2 = b2_hash_pair(d0.h, d1.h);
+  const b2digest d2 = b2_hash_pair<WIDE>(d0.h, d1.h);
   store8(tree + (N / 4 + i) * 8, d2.h);
   if (i == 0) {
     uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -426,7 +430,10 @@ hipError_t shk_stark_inv_z2(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_h
 }
 
 hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st) {
-  hipLaunchKernelGGL(stark_leaves_kernel, dim3(grid_for(a.n >> 2), a.batch), dim3(TPB), 0, st, a, d_nodes);
+  if ((a.n >> 2) * a.batch >= STARK_WIDE_THREADS)
+    hipLaunchKernelGGL(stark_leaves_kernel<true>, dim3(grid_for(a.n >> 2), a.batch), dim3(TPB), 0, st, a, d_nodes);
+  else
+    hipLaunchKernelGGL(stark_leaves_kernel<false>, dim3(grid_for(a.n >> 2), a.batch), dim3(TPB), 0, st, a, d_nodes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return shk_merkle_upper_levels(a.n, a.batch, d_nodes, st);
@@ -441,12 +448,21 @@ hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint
 hipError_t shk_stark_lincomb_tree(const StarkArgs& a, const fp* d_scal, fp* d_l, uint32_t* d_lnodes, hipStream_t st) {
   if (a.n < 4) return hipErrorInvalidValue;
   const dim3 grid(grid_for(a.n >> 2), a.batch);
+  const bool wide = (a.n >> 2) * a.batch >= STARK_WIDE_THREADS;
+#define SHK_LINCOMB(W)                                                                                              \
+  do {                                                                                                              \
+    if (wide)                                                                                                       \
+      hipLaunchKernelGGL((stark_lincomb_leaves_kernel<W, true>), grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((stark_lincomb_leaves_kernel<W, false>), grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes); \
+  } while (0)
   if (a.width == 1)
-    hipLaunchKernelGGL(stark_lincomb_leaves_kernel<1>, grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);
+    SHK_LINCOMB(1);
   else if (a.width == 2)
-    hipLaunchKernelGGL(stark_lincomb_leaves_kernel<2>, grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);
+    SHK_LINCOMB(2);
   else
-    hipLaunchKernelGGL(stark_lincomb_leaves_kernel<0>, grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);
+    SHK_LINCOMB(0);
+#undef SHK_LINCOMB
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return shk_merkle_upper_levels(a.n, a.batch, d_lnodes, st);
