@@ -72,10 +72,11 @@ B2_HD void b2_compress_cpp(uint32_t h[8], const uint32_t m[16], uint32_t t, bool
   h[7] ^= v7 ^ v15;
 }
 
-// Throughput form (device only): the ten rounds as generated asm blocks (gen_blake2s_asm.py: four columns in lock-step, plain
-// two-operand adds, a taken branch to the next instruction after every group of rotates -- 51 against 40 G pair-hashes/s for the
-// compiler's schedule of the C++ rounds on the bare hash loop, profiles/r04_blake2s_issue_rate_study.txt).  It wins where
-// many waves hash at once (the wide Merkle levels, the STARK leaf kernels) and loses where one wave per SIMD walks a chain.
+// Throughput form (device only): the ten rounds as generated asm blocks (gen_blake2s_asm.py: four columns in lock-step, a + b + m as
+// one v_add3_u32, a taken branch to the next instruction after every group of rotates -- 48 G pair-hashes/s on the bare hash loop
+// against 40 for the compiler's schedule of the C++ rounds; the two-adds form reaches 51 there but loses in sustained, power-limited
+// runs, where the instruction count decides; profiles/r04_blake2s_issue_rate_study.txt).  It wins where many waves hash at once
+// (the wide Merkle levels, the STARK leaf kernels) and loses where one wave per SIMD walks a chain.
 // -DB2_NO_ASM keeps the C++ rounds everywhere (A/B builds).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(B2_NO_ASM)
 #define B2_ASM_ROUNDS 1

@@ -14,11 +14,15 @@ Bare pair-hash loop (tools/blake_occ.hip, G hashes/s, 4-8 waves per SIMD):
     compiler, C++ rounds                                   39.8-40.1
     lock-step, two adds, no branch                          35.7
     lock-step, v_add3, VOP2 ops in 8-byte encoding          43.5-44.4      (uniform instruction size helps without branches)
-    lock-step, v_add3, branch after the rotates             48.0-48.3
-    lock-step, two adds, branch after the rotates           50.3-51.3      <- emitted by default
+    lock-step, v_add3, branch after the rotates             48.0-48.3      <- emitted by default (see below)
+    lock-step, two adds, branch after the rotates           50.3-51.3      (--two-adds)
     model: 800 fast + 320 slow instructions at 0.9 / 1.72 ns     51.6
     lock-step, two adds, branches, rotr 16 as two v_xor_b32_sdwa     46.8-47.4      (--sdwa16: the sub-dword forms issue at the slow rate)
---add3 / --e64 / --no-branch / --branch-after=... / --align / --sdwa16 select the other forms for A/B builds.
+Which of the last two: the bare loop runs a few milliseconds, inside the chip's boost window.  A SUSTAINED run is power-limited (the package
+sits at 1.3-1.4 kW, profiles/r04_power_and_clocks.txt), and there the form with FEWER instructions wins although it issues more slowly:
+ten Merkle commits of 2^24 leaves 0.587-0.601 ms against 0.604-0.614, config 5 4869-4979 against 4848-4901 proofs/s (A/B, alternating,
+one session; profiles/r04_blake2s_issue_rate_study.txt).
+--add3 / --two-adds / --e64 / --no-branch / --branch-after=... / --align / --sdwa16 select the other forms for A/B builds.
 
 Each half-round (4 x G) is one asm block: 16 state registers in/out, 8 message words in (24 operands; inline asm allows 30).
 The blocks are not volatile: the compiler may move whole blocks of two independent hashes past each other, never inside.
@@ -44,13 +48,14 @@ COLS = [(0, 4, 8, 12), (1, 5, 9, 13), (2, 6, 10, 14), (3, 7, 11, 15)]
 DIAGS = [(0, 5, 10, 15), (1, 6, 11, 12), (2, 7, 8, 13), (3, 4, 9, 14)]
 
 
-ADD3 = False   # a = a + b + x as one v_add3_u32 (VOP3) instead of two v_add_u32
+ADD3 = True    # a = a + b + x as one v_add3_u32 (VOP3) instead of two v_add_u32 (--two-adds: the other form)
 E64 = False    # the VOP2 adds / xors in their 8-byte VOP3 encoding
 ALIGN = False  # every block starts 8-byte aligned (.p2align 3): with four columns per line the 8-byte instructions stay aligned
 SDWA16 = False # d = rotr(d ^ a, 16) as two sub-dword xors into a scratch register (v_xor_b32_sdwa) instead of v_xor_b32 + v_alignbit_b32
 BRANCH = 0     # a taken s_branch to the next instruction after every BRANCH lines of a half-round (0 = none)
 BRANCH_OP = "s_branch 0"
-BRANCH_AFTER = (4, 7, 11, 14)  # a taken s_branch to the next instruction after these lines (1-based) of a half-round: the rotates
+BRANCH_AFTER = (3, 6, 9, 12)  # a taken s_branch to the next instruction after these lines (1-based) of a half-round: the rotates
+# (two-adds form: lines 4, 7, 11, 14)
 
 
 def half_round(groups):
@@ -225,6 +230,9 @@ def main():
     if "--add3" in sys.argv:
         ADD3 = True
         BRANCH_AFTER = (3, 6, 9, 12)
+    if "--two-adds" in sys.argv:
+        ADD3 = False
+        BRANCH_AFTER = (4, 7, 11, 14)
     if "--e64" in sys.argv:
         E64 = True
     if "--no-branch" in sys.argv:
