@@ -379,3 +379,52 @@ def test_ntt_tile_mapping_keeps_barrier_free_exchanges_inside_a_wave(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip() == "37 tile shapes, 85 barrier-free exchanges, 0 failures"
+
+
+def test_dpp_reads_keep_their_distance_from_the_producer(tmp_path):
+    """gfx950: a VALU write of a VGPR followed by a DPP read of it needs two wait states.  The compiler takes care of that in its own
+    code, but not inside inline asm -- and the quad-lane BLAKE2s half-rounds (csrc/blake2s.cuh: B2Q_HALF) are asm blocks whose DPP
+    reads rely on being at least that far behind the last writer, including whatever the compiler puts right in front of a block.
+    Checked on the compiled ISA of kernels.hip (every kernel that hashes in the serial form): for every *_dpp instruction, none of the
+    instructions inside the two preceding wait states writes its DPP source."""
+    import re, subprocess
+    asm = tmp_path / "kernels.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-S", "--cuda-device-only",
+                           "-I", os.path.join(ROOT, "starks_amd", "csrc"), os.path.join(ROOT, "starks_amd", "csrc", "kernels.hip"),
+                           "-o", str(asm)], stderr=subprocess.DEVNULL)
+    ins = []
+    for ln in open(asm):
+        ln = ln.split(";")[0].strip()
+        if ln and re.match(r"^[vs]_|^ds_|^global_|^buffer_|^scratch_|^flat_", ln):
+            ins.append(ln)
+
+    def regs(tok):
+        tok = tok.strip()
+        m = re.fullmatch(r"v(\d+)", tok)
+        if m:
+            return {int(m.group(1))}
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+    checked = 0
+    for i, ln in enumerate(ins):
+        op = ln.split()[0]
+        if not op.endswith("_dpp"):
+            continue
+        ops = [t for t in ln[len(op):].split(" quad_perm")[0].split(" row_")[0].split(",")]
+        src = regs(ops[1])  # VOP1 / VOP2 DPP: vdst, src0 (the DPP operand), [src1]
+        assert src, ln
+        checked += 1
+        waits, j = 0, i - 1
+        while waits < 2 and j >= 0:
+            prev = ins[j]
+            pop = prev.split()[0]
+            if pop == "s_nop":
+                waits += int(prev.split()[1], 0) + 1
+            else:
+                if pop.startswith("v_") and not pop.startswith("v_cmp"):
+                    dst = regs(prev[len(pop):].split(",")[0])
+                    assert not (dst & src), "DPP hazard: '%s' reads what '%s' wrote %d instruction(s) earlier" % (ln, prev, i - j)
+                waits += 1
+            j -= 1
+    assert checked >= 80 * 4  # 80 DPP reads per compression, in the top kernels (three leaf modes x two widths) and the sampling kernels
