@@ -433,10 +433,17 @@ inline hipError_t shk_launch_tile_kernel(void (*k)(NttPassArgs), std::atomic<uin
   if (e != hipSuccess) return e;
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+#if defined(SHK_LDS_PAD_KIB)
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + ((size_t)SHK_LDS_PAD_KIB << 10)));
+#else
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+#endif
     if (e != hipSuccess) return e;
     attr_done.fetch_or(bit, std::memory_order_release);
   }
+#if defined(SHK_LDS_PAD_KIB)  // diagnostic builds: a larger LDS allocation = fewer resident workgroups (occupancy experiments)
+  lds_bytes += (size_t)SHK_LDS_PAD_KIB << 10;
+#endif
   const uint64_t tiles = (a.total + ((1ull << log_t) - 1)) >> log_t;
   if (tiles == 0) return hipSuccess;
   if (tiles > 0x7ffffff0ull) return hipErrorInvalidValue;
