@@ -17,7 +17,7 @@ columns per launch sequence), `fri_commit_ms_2^20_trace` / `fri_commit_ms_2^14_t
 
 Workload `c5` (BASELINE configs[4]): `--units` (512) independent 2^16-step MiMC STARK proofs (STARK.mk_proof,
 stark.py:233-279; unit j = test_stark.py:265-293 started from 3 + j), sharded over the ranks by proof index
-(starks_amd/batch.py:shard), `--chunk` (128) proofs per batched launch, the launches dealt in turn to `--c5-streams` (2) library
+(starks_amd/batch.py:shard), `--chunk` (128; fewer when a rank's shard would leave a context idle) proofs per batched launch, the launches dealt in turn to `--c5-streams` (2) library
 contexts; a step = the whole batch once; `value` = proofs/s; strong
 scaling; the only exchange is one all_gather of the 64-byte proof headers (m_root | l_root) per step (RCCL).  Every run of
 the default workload also runs three such steps after its timed region and reports it under `c5` / `c5_proofs_per_s`, so
@@ -552,7 +552,10 @@ def main():
         """K timed steps of the many-proof workload; returns the result dict (rank-independent fields agree on all ranks)."""
         steps = 1 << args.logsteps
         mine = shard(args.units, rank, world)
-        sh = ProofShard(dev, mine, steps, 8, args.chunk, args.c5_streams)
+        # proofs per batched launch: --chunk, but never so many that one of the contexts stays idle (a rank of the 8-GPU run holds 64
+        # units: two launches of 32 on two contexts measure 1 % ahead of one launch of 64; 128 units: 64 x 2 against 128 x 1 likewise)
+        chunk = min(args.chunk, max(1, (len(mine) + args.c5_streams - 1) // max(1, args.c5_streams)))
+        sh = ProofShard(dev, mine, steps, 8, chunk, args.c5_streams)
         heads = None
         for _ in range(warm_k):
             sh.prove_all()
@@ -583,7 +586,7 @@ def main():
         ok = all_ok(chk["batch_equals_single"] and chk["verifies"] is not False and chk["equals_one_context_run"] and
                     len(set(heads)) == len(heads))
         n = steps * 8
-        res = {"units": args.units, "trace_steps": steps, "domain": n, "proofs_per_launch": args.chunk,
+        res = {"units": args.units, "trace_steps": steps, "domain": n, "proofs_per_launch": chunk,
                "proofs_per_s": args.units * steps_k / dt, "ms_per_step": dt / steps_k * 1e3, "ms_per_proof": dt / steps_k / args.units * 1e3,
                "n_gpus": world, "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)],
                "proof_bytes": sh.plen, "headers_sha256": hashlib.sha256(b"".join(heads)).hexdigest(),
@@ -610,7 +613,7 @@ def main():
             "config": {"workload": "configs[4]: batch of %d independent 2^%d-step MiMC STARK proofs (STARK.mk_proof, width 2, "
                                    "8x extension, 80 spot checks, FRI 40 samples), sharded by proof index over %d GPU(s), %d "
                                    "proofs per batched launch; a step proves the whole batch once" %
-                                   (args.units, args.logsteps, world, args.chunk),
+                                   (args.units, args.logsteps, world, res["proofs_per_launch"]),
                        "units": args.units, "trace_steps": steps, "parallelism": "proof sharding x%d" % world},
             "c5": res, "c5_proofs_per_s": res["proofs_per_s"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
