@@ -67,8 +67,8 @@ int main() {
       for (int i = 0; i < 8; ++i) half.v[i] = (q[i] >> 1) | (i < 7 ? q[i + 1] << 31 : 0u);
     }
     inv4 = fp_mul(half, half);
-    const fp chk = fp_canon(fp_mul(inv4, four));
-    if (memcmp(&chk, &(const fp&)fp_one(), sizeof chk)) { printf("4^-1 is wrong\n"); ++bad; }
+    const fp chk = fp_canon(fp_mul(inv4, four)), one = fp_one();
+    if (memcmp(&chk, &one, sizeof chk)) { printf("4^-1 is wrong\n"); ++bad; }
     for (int it = 0; it < 200000; ++it) {
       fp x;
       for (int i = 0; i < 8; ++i) x.v[i] = rnd();
