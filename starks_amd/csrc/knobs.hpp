@@ -14,6 +14,8 @@
 //   STARKHIP_XCD_SWZ=0|1|2|3       workgroup -> tile mapping over the 8 XCDs (ntt_kernels.cuh:shk_launch_tile_kernel)
 //   STARKHIP_TW2_MAX_LOG=k         row-major inter-pass twiddle tables up to 2^k entries (default 24), else the power-table lookup
 //   STARKHIP_PLAN_CACHE_MB=m       initial plan-cache budget of a context
+//   STARKHIP_NTT_NARROW_TILES=k    passes of at most k 1024-element tiles (and radix <= 2^10) run in the one-butterfly-per-thread form
+//                                  (ntt_narrow_pass_kernel; default 256 = the CUs of the chip; 0 = never)
 // All of them exist for the parity tests over alternate plans (tests/test_gpu_parity.py::test_alternate_ntt_plans_parity,
 // tools/stress_plans.py) and for A/B measurements; the defaults are the measured best.
 #pragma once
@@ -32,6 +34,7 @@ struct ShkKnobs {
   int n_radices = 0;         // 0: not given (or malformed)
   int radices[4] = {0, 0, 0, 0};
   int radix_sum = 0;
+  long narrow_tiles = 256;   // 0: the narrow form is never used
 };
 
 namespace shk_knobs_detail {
@@ -67,6 +70,10 @@ inline void parse(ShkKnobs* k) {
   if (const char* e = getenv("STARKHIP_PLAN_CACHE_MB")) {
     const long v = atol(e);
     if (v >= 0) k->plan_cache_mb = v;
+  }
+  if (const char* e = getenv("STARKHIP_NTT_NARROW_TILES")) {
+    const long v = atol(e);
+    k->narrow_tiles = v < 0 ? 0 : v;
   }
   if (const char* e = getenv("STARKHIP_NTT_RADICES")) {
     int r[4] = {0, 0, 0, 0}, cnt = 0, sum = 0;

@@ -16,6 +16,22 @@ hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
                                 LAST, a, st);
 }
 
+// narrow launches (ntt_kernels.cuh): at most kn.narrow_tiles tiles of 1024 elements, radix <= 2^10
+template <int LOG_R, bool LAST>
+bool launch_narrow(const NttPassArgs& a, hipStream_t st, hipError_t* err) {
+  if constexpr (LOG_R <= 10) {
+    const ShkKnobs& kn = shk_knobs();
+    constexpr int LOG_T = 10 - LOG_R;
+    const uint64_t tiles = (a.total + ((1ull << LOG_T) - 1)) >> LOG_T;
+    if (kn.narrow_tiles <= 0 || tiles == 0 || tiles > (uint64_t)kn.narrow_tiles) return false;
+    if (a.pass_index < 8 && kn.tile_logs[a.pass_index]) return false;  // a forced tile size means the tile-pass kernels
+    hipLaunchKernelGGL((ntt_narrow_pass_kernel<LOG_R, LOG_T, LAST>), dim3((unsigned)tiles), dim3(1u << (LOG_R + LOG_T - 1)), 0, st, a);
+    *err = hipGetLastError();
+    return true;
+  }
+  return false;
+}
+
 // The FIRST column pass of a long transform (P = 1: the rows of a tile are n / R elements apart) gets 2048-element tiles once that
 // distance reaches 2 MiB (n / R >= 2^16): twice the columns per row (256-byte segments at radix 2^8) are worth + 3.6 % on a
 // 2^24-point transform and + 4 % on two of them (profiles/r03_first_pass_tile_2p24.txt); below that distance the 1024-element
@@ -24,6 +40,8 @@ hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
 template <int LOG_R, bool LAST>
 hipError_t launch(const NttPassArgs& a, hipStream_t st) {
   const ShkKnobs& kn = shk_knobs();
+  hipError_t ne = hipSuccess;
+  if (launch_narrow<LOG_R, LAST>(a, st, &ne)) return ne;
   if (const int f = a.pass_index < 8 ? kn.tile_logs[a.pass_index] : 0) {
     if (f == 12 && LOG_R >= 4) return launch_tile<LOG_R, LAST, 12>(a, st);
     if (f == 11) return launch_tile<LOG_R, LAST, 11>(a, st);
@@ -43,6 +61,8 @@ hipError_t launch(const NttPassArgs& a, hipStream_t st) {
 template <int LOG_R, bool LAST>
 hipError_t launch_big(const NttPassArgs& a, hipStream_t st) {
   const ShkKnobs& kn = shk_knobs();
+  hipError_t ne = hipSuccess;
+  if (launch_narrow<LOG_R, LAST>(a, st, &ne)) return ne;
   if (const int f = a.pass_index < 8 ? kn.tile_logs[a.pass_index] : 0) {
     if (f == 12) return launch_tile<LOG_R, LAST, 12>(a, st);
     if (f == 11) return launch_tile<LOG_R, LAST, 11>(a, st);

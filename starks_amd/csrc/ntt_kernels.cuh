@@ -417,6 +417,114 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
   ntt_pass_body<LOG_R, LOG_T, LAST>(a);
 }
 
+// ---- narrow launches -----------------------------------------------------------------------------------------------------
+// A pass over fewer tiles than the chip has CUs is a latency chain, not a throughput problem: every workgroup is alone on its CU, a
+// lone wave issues an instruction every ~2 ns whatever it does, and ntt_pass_body gives a thread 2 butterflies per level (4
+// elements, 14-20 butterflies and 4 inter-pass products per pass = 11-20 us for a radix 2^7..2^9 pass).  Here a thread owns ONE
+// butterfly per level (twice the threads per tile, 512 for 1024 elements): the pair (i, i + half) of level q = log2(half) is read from
+// the tile's LDS image, combined, and written back in place; one workgroup barrier per level; the first level reads global memory,
+// the last one writes it (same addresses, twiddles and results as ntt_pass_body: DIF, position i holds frequency bitrev(i)).
+// Used below STARKHIP_NTT_NARROW_TILES tiles per launch (knobs.hpp; small transforms: the commits and proofs of 2^14..2^16-step traces).
+template <int LOG_R, int LOG_T, bool LAST>
+__global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 1)) ntt_narrow_pass_kernel(NttPassArgs a) {
+  static_assert(LOG_R >= 2 && LOG_R <= 10 && LOG_T >= 0 && LOG_R + LOG_T == 10, "1024-element tiles");
+  __shared__ __attribute__((aligned(16))) uint4 lds[2 << (LOG_R + LOG_T)];
+  constexpr int R = 1 << LOG_R;
+  const uint32_t tid = threadIdx.x;
+  // Which butterfly (column / row t, pair index p) a thread takes may change from level to level: everything goes through the LDS
+  // image behind a workgroup barrier.  Column pass: adjacent lanes take adjacent columns throughout (32 contiguous bytes each, in
+  // the loads and in the stores).  Row pass: adjacent lanes run along the contiguous row for the loads of the first level and take
+  // adjacent rows afterwards, so that the T outputs of one frequency land on T adjacent addresses (as in ntt_pass_body).
+  const uint32_t t_in = LAST ? tid >> (LOG_R - 1) : tid & ((1u << LOG_T) - 1u);
+  const uint32_t p_in = LAST ? tid & (R / 2 - 1) : tid >> LOG_T;
+  const uint32_t t = tid & ((1u << LOG_T) - 1u), p = tid >> LOG_T;
+  const uint64_t tile0 = (uint64_t)blockIdx.x << LOG_T;
+  // threads past the end work on a copy of the last column / row and store nothing
+  const uint64_t col_in = tile0 + t_in < a.total ? tile0 + t_in : a.total - 1;
+  const bool active = tile0 + t < a.total;
+  const uint64_t col = active ? tile0 + t : a.total - 1;
+  uint64_t gbase_in, gbase = 0, obase = 0, sbase_in, j2 = 0;
+  if (LAST) {
+    auto row_of = [&](uint64_t c, uint64_t* bb) {  // rows enumerated with the first pass's digit fastest, as in ntt_pass_body
+      *bb = c >> a.log_P;
+      const uint32_t pp = (uint32_t)(c & ((1ull << a.log_P) - 1));
+      const uint32_t lr1 = a.ndig ? a.dig_log[0] : 0;
+      const uint32_t k1 = pp & ((1u << lr1) - 1u), rst = pp >> lr1;
+      return (k1 << (a.log_P - lr1)) | rst;
+    };
+    uint64_t b_in, b_out;
+    const uint32_t row_in = row_of(col_in, &b_in), row = row_of(col, &b_out);
+    uint32_t sh = a.log_P, wl = 0, acc = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; ++d) {
+      if (d < a.ndig) {
+        sh -= a.dig_log[d];
+        acc |= ((row >> sh) & ((1u << a.dig_log[d]) - 1u)) << wl;
+        wl += a.dig_log[d];
+      }
+    }
+    gbase_in = (b_in << a.log_n) + ((uint64_t)row_in << LOG_R);
+    obase = (b_out << a.log_n) + acc;
+    sbase_in = b_in * a.src_n;
+  } else {
+    j2 = col & ((1ull << a.log_S) - 1);
+    gbase = ((col >> a.log_S) << (LOG_R + a.log_S)) + j2;
+    gbase_in = gbase;
+    sbase_in = (col >> a.log_S) * a.src_n;
+  }
+  auto fetch = [&](uint32_t i) {
+    if (a.src_n) {  // zero-padded source (first pass): points at or beyond src_n are zero and are not read
+      const uint64_t off = LAST ? (uint64_t)i : (((uint64_t)i << a.log_S) + j2);
+      const bool in = off < a.src_n;
+      fp v = fp_load(a.src + sbase_in + (in ? off : 0));
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v.v[w] = in ? v.v[w] : 0u;
+      return v;
+    }
+    return LAST ? fp_load(a.src + gbase_in + i) : fp_load(a.src + gbase_in + ((uint64_t)i << a.log_S));
+  };
+  fp x0, x1;
+  uint32_t i_lo = 0;
+#pragma unroll
+  for (int q = LOG_R - 1; q >= 0; --q) {
+    const uint32_t half = 1u << q;
+    const uint32_t tq = q == LOG_R - 1 ? t_in : t, pq = q == LOG_R - 1 ? p_in : p;
+    i_lo = ((pq >> q) << (q + 1)) | (pq & (half - 1u));
+    const uint32_t i_hi = i_lo | half;
+    const uint32_t s_lo = lds_slot((i_lo << LOG_T) | tq), s_hi = lds_slot((i_hi << LOG_T) | tq);
+    fp u, v;
+    if (q == LOG_R - 1) {
+      u = fetch(i_lo);
+      v = fetch(i_hi);
+    } else {
+      u = lds_get_at(lds, s_lo);
+      v = lds_get_at(lds, s_hi);
+    }
+    x0 = fp_add(u, v);
+    x1 = fp_sub(u, v);
+    if (q > 0) {
+      x1 = fp_mul2(x1, fp2_load(a.wR + ((i_lo & (half - 1u)) << (LOG_R - 1 - q))));  // w_R^((i mod half) * R / (2 half))
+      lds_put_at(lds, s_lo, x0);
+      lds_put_at(lds, s_hi, x1);
+      __syncthreads();
+    }
+  }
+  if (!active) return;
+  // position i of the DIF output holds frequency k = bitrev(i); this thread ends with positions i_lo (even) and i_lo + 1
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t k = __brev(i_lo | (uint32_t)h) >> (32 - LOG_R);
+    fp v = h ? x1 : x0;
+    if (LAST) {
+      if (a.scale) v = fp_mul(v, fp_load(a.scale));
+      fp_store(a.dst + obase + ((uint64_t)k << a.log_P), v);
+    } else {
+      const fp tw = a.tw2 ? fp_load(a.tw2 + ((uint64_t)k << a.log_S) + j2) : tw_lookup(a, j2 * k);
+      fp_store(a.dst + gbase + ((uint64_t)k << a.log_S), fp_mul(v, tw));
+    }
+  }
+}
+
 // ---- launching a tile pass (any kernel built on ntt_pass_body) --------------------------------------------------------------
 // Tiles narrower than 128 bytes (T < 4: the big-radix passes) share their cache lines with the neighbouring tile; workgroups
 // are dealt to the 8 XCDs round-robin, so neighbours would sit behind different L2s and every line would be fetched (or

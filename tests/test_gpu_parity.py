@@ -1119,10 +1119,16 @@ def test_bench_rccl_collectives_with_one_rank(sa, workload):
     {"STARKHIP_NTT_RADICES": "6,6,4", "STARKHIP_TILE_LOG": "11"},     # 2^16 in three passes, 2048-element tiles
     {"STARKHIP_XCD_SWZ": "3"},                                        # column tiles in sharer-fastest order
     {"STARKHIP_TILE_LOGS": "11,9,10", "STARKHIP_TW2_MAX_LOG": "20"},  # a tile size per pass; small row tables (lookup fallback)
-], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "sharer_order", "per_pass_tiles"])
+    {"STARKHIP_NTT_NARROW_TILES": "100000000"},                       # every pass of radix <= 2^10 in the one-butterfly-per-thread form
+    {"STARKHIP_NTT_NARROW_TILES": "100000000", "STARKHIP_NTT_RADICES": "5,5,4,3", "STARKHIP_TW2_MAX_LOG": "12"},  # ... four passes of 2^17, lookups
+], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "sharer_order", "per_pass_tiles", "narrow_everywhere", "narrow_5-5-4-3"])
 def test_alternate_ntt_plans_parity(sa, env):
     """Every decomposition the plan / tile knobs can select gives the same bytes: the NTT golden vectors (reference digests to
-    2^20), every size against the oracle and the 2^22 / 2^24 digests, in a child process with the knobs set."""
+    2^20), every size against the oracle and the 2^22 / 2^24 digests, in a child process with the knobs set.  (The plan / tile
+    variants run with the narrow-launch form off, so that the tile-pass kernels also serve the small sizes; the last two force
+    that form for every launch, the 2^24-point digests included.)"""
+    env = dict(env)
+    env.setdefault("STARKHIP_NTT_NARROW_TILES", "0")
     import subprocess, sys
     from conftest import ROOT
     sel = ("test_ntt_golden_vectors or test_ntt_every_size_vs_oracle or test_ntt_padding_and_batch or "
