@@ -254,7 +254,12 @@ def extras(dev, quick):
         "ms_per_batch": round(ms, 4), "proofs_per_s": bsz / ms * 1e3, "ms_per_proof": round(ms / bsz, 5)}
     dev.free(dc)
     dev.free(dp)
-    # ---- FRI commit: 2^14-step (config 3) and 2^20-step MiMC trace, 8x extension ---------------------
+    # ---- FRI commit: 2^14-step (config 3), 2^16-step (config 5) and 2^20-step (the metric) traces, 8x extension --------
+    # every proof is compared with the bytes oracle/oracle.c:fri_rec wrote for the same input (tests/golden/fri_large.json)
+    try:
+        fri_gold = {c["logsteps"]: c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "fri_large.json")))["cases"]}
+    except Exception:
+        fri_gold = {}
     for logsteps in ([14] if quick else [14, 16, 20]):
         steps, ext = 1 << logsteps, 8
         n = steps * ext
@@ -275,10 +280,13 @@ def extras(dev, quick):
         ms_dense = dev.timed(lambda: dev.ck(L.sh_dev_fri_prove(ctx, dc, n, w, steps, ext, 40, 1, dp), "fri"), 5)
         dense = ctypes.create_string_buffer(plen)
         dev.ck(L.sh_dev_download(ctx, dp, dense, plen), "dl")
+        sha = hashlib.sha256(short.raw).hexdigest()
+        gold = fri_gold.get(logsteps)
         out["fri_commit_steps_2^%d" % logsteps] = {"ms": round(ms, 4), "ms_from_padded_vector": round(ms_dense, 4), "domain": n,
                                                    "proof_bytes": plen, "algorithmic_GBps": 203.0 * n / ms / 1e6,
-                                                   "same_bytes_both_ways": short.raw == dense.raw,
-                                                   "proof_sha256": hashlib.sha256(short.raw).hexdigest()}
+                                                   "same_bytes_both_ways": short.raw == dense.raw, "proof_sha256": sha,
+                                                   "matches_fixture": (sha == gold["proof_sha256"] and gold["seed"] == 0xF51) if gold else None,
+                                                   "fixture": "tests/golden/fri_large.json (oracle/oracle.c:fri_rec)" if gold else None}
         dev.free(dc)
         dev.free(dp)
     # ---- whole prover: STARK.mk_proof (stark.py:233-279) for the reference's MiMC formulation, width 2 ------------
@@ -354,10 +362,36 @@ def cpu_baseline(logn, vectors, budget_s=10.0):
                   (cores, 1 << log_stride, log_stride, logn, sub, 1 << log_stride, cores - 1,
                    "/".join(str(r["reps"]) for r in res), max(r["seconds"] for r in res), wall, sub, logn, log_stride))
     return {"value": rate, "unit": "elements/s", "cores": cores, "kind": "port", "sample": sample,
-            "roundtrip_ok": all(r["roundtrip_ok"] for r in res), "digest": res[0]["fwd_sha256"] if log_stride == 0 else None}
+            "roundtrip_ok": all(r["roundtrip_ok"] for r in res), "digests": [r["fwd_sha256"] for r in res],
+            "sub_logn": sub, "log_stride": log_stride}
 
 
-def cpu_baseline_c5(steps, ext=8):
+def gpu_digests_of_cpu_sample(dev, logn, cpu):
+    """The forward transforms the CPU leg ran (cpu_baseline: vector b whole, or the branch x[o::2^log_stride] of vector 0), on the
+    GPU through the host-buffer entry point, as SHA-256 of the wire bytes -- what `cpu_baseline.digest_matches_gpu` compares."""
+    import numpy as np
+    L, ctx = dev.L, dev.ctx
+    sub, ls, k = cpu["sub_logn"], cpu["log_stride"], len(cpu["digests"])
+    n, m = 1 << logn, 1 << sub
+    got = []
+    out = ctypes.create_string_buffer(32 * m)
+    root = root_of(m).to_bytes(32, "big")
+    if ls == 0 and k != 1:
+        return None  # (several whole vectors: the seeded fill has no offset argument, only vector 0 is regenerated here)
+    dx = dev.alloc(32 * n)
+    dev.ck(L.sh_dev_fill_seeded(ctx, dx, n, 0x5eed), "fill")
+    host = ctypes.create_string_buffer(32 * n)
+    dev.ck(L.sh_dev_to_wire(ctx, dx, host, n), "dl")
+    dev.free(dx)
+    x = np.frombuffer(host, dtype=np.uint8).reshape(m, 1 << ls, 32)  # ls == 0: the vector itself
+    for o in range(k):
+        branch = np.ascontiguousarray(x[:, o, :]).tobytes()  # x[o::2^ls]
+        dev.ck(L.sh_ntt(ctx, branch, m, out, m, root, 0), "ntt")
+        got.append(hashlib.sha256(out.raw).hexdigest())
+    return got
+
+
+def cpu_baseline_c5(steps, ext=8, dev=None):
     """Config 5's CPU baseline: the oracle has no whole-prover in C (the STARK oracle is coefficient-form Python, O(n^2));
     what it can time at this size is the FRI commit of one unit's trace polynomial (oracle/oracle.c:fri_rec, the
     reference's algorithm) -- a LOWER bound of one proof's CPU cost, stated as such."""
@@ -368,9 +402,18 @@ def cpu_baseline_c5(steps, ext=8):
     wire = b"".join(v.to_bytes(32, "big") for v in trace)
     t0 = time.time()
     coeffs = coracle.fft_bytes(wire, steps, pow(g2, ext, P), inverse=True)
-    coracle.fri_prove_flat(coeffs, g2, steps, ext, 40)
+    flat = coracle.fri_prove_flat(coeffs, g2, steps, ext, 40)
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+    same = None
+    if dev is not None:  # the same commit on the GPU (host-buffer entry points): the CPU leg's bytes are the library's bytes
+        n = steps * ext
+        gc = ctypes.create_string_buffer(32 * steps)
+        dev.ck(dev.L.sh_ntt(dev.ctx, wire, steps, gc, steps, pow(g2, ext, P).to_bytes(32, "big"), 1), "intt")
+        gp = ctypes.create_string_buffer(len(flat))
+        dev.ck(dev.L.sh_fri_prove(dev.ctx, gc.raw, steps, n, g2.to_bytes(32, "big"), steps, ext, 40, 1, gp, len(flat)), "fri")
+        same = gc.raw == coeffs and gp.raw == flat
+    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": 1, "kind": "port", "proof_matches_gpu": same,
+            "proof_sha256": hashlib.sha256(flat).hexdigest(),
             "sample": "one unit: inverse NTT of the trace + FRI commit (N = %d) with oracle/oracle.c, %.1f s; this is only "
                       "the FRI part of a proof (a lower bound of the CPU cost: the reference's quotient construction is "
                       "O(n^2) and not runnable at this size)" % (steps * ext, dt)}
@@ -476,6 +519,8 @@ def main():
                     "kernel trace to the timed workload's launches)")
     ap.add_argument("--quick", action="store_true", help="smaller secondary legs / c5 shape")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (profiling runs)")
+    ap.add_argument("--no-alu-peak", action="store_true", help="do not start tools/alu_mix_bench (profiling runs: its launches would "
+                    "land in the profiled session's kernel trace)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse "
                     "the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--dist-timeout", type=float, default=900.0, help="seconds a collective may wait for the other ranks")
@@ -624,7 +669,7 @@ def main():
                                  "combination kernels have no 8(d) figure); integer-VALU / BLAKE2s-ALU bound, not HBM bound"},
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_c5(steps)
+            line["cpu_baseline"] = cpu_baseline_c5(steps, dev=dev)
         if rank == 0:
             emit(line)
         if use_dist:
@@ -715,9 +760,9 @@ def main():
             "parallelism": "independent vectors x%d" % world},
         "field_mul_eq_per_s": (n // 2) * args.logn * 2 * B * args.steps * world / dt_max,
         "check": {"roundtrip_ok": ok, "fwd_sha256": fwd_digest, "matches_fixture": golden_ok, "fixture": golden_src},
-        # `roofline` keeps the metric's own quantity -- algorithmic HBM bytes against the 8 TB/s peak -- but what binds this kernel is
-        # the integer-VALU issue rate (roofline_alu below, completed on rank 0): `bound` says so
-        "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `roofline` is the metric's own quantity -- algorithmic HBM bytes against the 8 TB/s peak (bound / achieved / peak / unit / frac
+        # all speak of HBM); what binds this kernel is the integer-VALU issue rate: `binding_resource` and roofline_alu below
+        "roofline": {"bound": "hbm", "binding_resource": "integer VALU issue (see roofline_alu)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                      "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 64.0 * n * B / passes,
@@ -734,11 +779,16 @@ def main():
     if lane_instr:
         # the roof that binds: VALU lane-instructions the transform executes (committed counters of this command) x elements/s
         # of THIS run, against the wall-clock issue peak of the pass's own instruction mix (tools/alu_mix_bench, run below)
-        line["roofline_alu"] = {"bound": "integer VALU issue", "unit": "T lane-ops/s",
+        knobs_set = sorted(k for k in os.environ if k.startswith("STARKHIP_") and k not in ("STARKHIP_DEVICE", "STARKHIP_LIB"))
+        line["roofline_alu"] = {"bound": "integer VALU issue", "unit": "T lane-ops/s", "derived": True,
+                                "derived_note": "achieved = a COMMITTED instruction count (lane_instructions_source) x this run's elements/s; "
+                                                "the count goes stale when kernels or plans change" +
+                                                ("; STARKHIP_* knobs are set (%s): the count may not describe this run" % ",".join(knobs_set)
+                                                 if knobs_set else ""),
                                 "lane_instructions_per_element_per_transform": lane_instr, "lane_instructions_source": lane_src,
                                 "achieved": lane_instr * (n * B * 2 * args.steps) / (ev_ms.value * 1e-3) / 1e12,
                                 "peak": None, "frac": None}
-    if rank == 0 and world == 1 and "roofline_alu" in line:
+    if rank == 0 and world == 1 and "roofline_alu" in line and not args.no_alu_peak:
         line["roofline_alu"].update(alu_mix_peak(line["roofline_alu"]["achieved"]))
     if rank == 0 and world == 1 and not args.no_single:
         # the other shapes of the metric: configs[1] literally (ONE 2^20-point pair: a launch's load / store phases are
@@ -805,9 +855,14 @@ def main():
         line["c5_proofs_per_s"] = res["proofs_per_s"]
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.logn, B)
-            dg = line["cpu_baseline"].pop("digest")
-            line["cpu_baseline"]["digest_matches_gpu"] = None if dg is None else dg == fwd_digest
+            cb = cpu_baseline(args.logn, B)
+            # the transforms the CPU leg timed, run on the GPU: every one of them must give the same bytes
+            gd = gpu_digests_of_cpu_sample(dev, args.logn, cb)
+            cb["digest_matches_gpu"] = None if gd is None else gd == cb["digests"]
+            cb["digests_compared"] = 0 if gd is None else len(gd)
+            for k_ in ("digests", "sub_logn", "log_stride"):
+                cb.pop(k_)
+            line["cpu_baseline"] = cb
         if not args.no_extras:
             line["extra"] = extras(dev, args.quick)
             k20 = "fri_commit_steps_2^20"

@@ -77,7 +77,6 @@ def lib():
         "sh_host_alloc": (i32, [c_p, u64, pp]),
         "sh_host_free": (i32, [c_p, c_p]),
         "sh_ntt_passes": (u32, [u64, u32]),
-        "sh_ntt_path_name": (ctypes.c_char_p, []),
         "sh_dev_download_2d": (i32, [c_p, c_p, u64, c_p, u64, u64]),
         "sh_dev_fill_seeded": (i32, [c_p, c_p, u64, u64]),
         "sh_dev_ntt": (i32, [c_p, c_p, c_p, u64, u32, u8p, i32]),

@@ -580,7 +580,9 @@ uint64_t fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {
 int fri_validate(uint64_t n, uint64_t maxdeg_plus_1, uint32_t exclude, uint32_t samples) {
   uint64_t nn = n, md = maxdeg_plus_1;
   bool first = true;
+  uint32_t rounds = 0;
   while (md > 16) {
+    if (++rounds > SHK_FRI_MAX_ROUNDS) return SH_ERR_UNSUPPORTED;  // FriSampleArgs holds that many rounds (checked BEFORE any launch)
     if (nn < 16) return SH_ERR_INVALID;            // the reference cannot merkelize a column of < 4 values
     if ((nn >> 2) >= (1ull << 24)) return SH_ERR_UNSUPPORTED;  // assert modulus < 2**24 (utils.py:69)
     const uint32_t s = first ? samples : 40;
@@ -635,8 +637,7 @@ int fri_rounds(sh_ctx* c, NttPlan* pl, FriBuffers fb, uint64_t n, uint64_t maxde
   sa.proof = d_proof;
   sa.proof_stride = stride;
   uint32_t ys_off = 0;
-  while (md > 16) {
-    if (round >= SHK_FRI_MAX_ROUNDS) return SH_ERR_UNSUPPORTED;
+  while (md > 16) {  // at most SHK_FRI_MAX_ROUNDS rounds: fri_validate has refused anything longer before the first launch
     const uint32_t s = round == 0 ? samples : 40;
     if (!have_tree) HIP_TRY(c, shk_merkelize(vals, false, nn, batch, tree, c->stream, false));  // m = merkelize(values), fri.py:224
     FoldArgs fa;
@@ -1423,10 +1424,6 @@ uint32_t sh_ntt_passes(uint64_t n, uint32_t batch) {
   (void)batch;  // one decomposition per size
   int r[4];
   return (uint32_t)shk_choose_radices(ilog2(n), r);
-}
-
-const char* sh_ntt_path_name(void) {
-  return "valu";  // the integer-VALU tile passes are the only path (the matrix-core placements: tools/not_kept/mfma)
 }
 
 uint64_t sh_fri_proof_len(uint64_t n, uint64_t maxdeg_plus_1, uint32_t samples) {

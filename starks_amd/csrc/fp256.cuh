@@ -436,17 +436,6 @@ __device__ __forceinline__ fp fp_load(const fp* p) {
   r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
   return r;
 }
-// the same with the non-temporal hint (global_load_dwordx4 ... nt): streams that are read once and should not displace the
-// lines other kernels are about to re-read (experiment knobs SHK_NT_* in ntt_kernels.cuh)
-__device__ __forceinline__ fp fp_load_nt(const fp* p) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4* q = reinterpret_cast<const u32x4*>(p);
-  const u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
-  fp r;
-  r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
-  r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-  return r;
-}
 __device__ __forceinline__ fp2 fp2_load(const fp2* p) {
   fp2 r;
   r.w = fp_load(&p->w);

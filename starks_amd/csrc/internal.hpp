@@ -29,9 +29,6 @@ struct NttPassArgs {
   uint32_t pass_index; // 0 = the first pass of the transform (experiments: STARKHIP_TILE_LOGS picks a tile size per pass)
   uint32_t xcd_per;   // 0: tile = blockIdx.x.  Else workgroups are dealt to the 8 XCDs round-robin and tile = (blockIdx.x & 7) *
                       // xcd_per + (blockIdx.x >> 3): adjacent tiles run on the SAME XCD (they share 128-byte lines when T < 4)
-  uint32_t sharers;   // column passes with xcd_per: the number of (vector, prefix block) pairs = total >> log_S, all of which
-                      // read the same tw2 rows; tiles are then enumerated sharer-fastest, so that the tiles that share a row
-                      // set run back to back behind one L2 (0: plain order)
 };
 
 // ---- ntt.hip ----------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 
 #include "blake2s.cuh"
 #include "internal.hpp"
+#include "wave_chunks.cuh"
 
 namespace {
 
@@ -104,13 +105,7 @@ __global__ void __launch_bounds__(TPB) pad_copy_kernel(const fp* src, fp* dst, u
 }
 
 // ---- Merkle tree ------------------------------------------------------------------------------------
-// LDS-transposed block I/O.  A thread that owns CH adjacent 16-byte chunks (a 128-byte row of four leaves, a
-// 64-byte node pair) would store them at a lane stride of CH*16 bytes: measured 2.5 TB/s for the permute4
-// gather against 5.7 TB/s when the same bytes leave lane-contiguously (tools/membench.hip).  The block therefore
-// parks its chunks in LDS (XOR-swizzled by bank row, conflict-free both ways) and moves them to / from global
-// memory 16 bytes per lane, 4 KiB per wave instruction group.
-__device__ __forceinline__ uint32_t chunk_swz(uint32_t c) { return (c & ~15u) | ((c & 15u) ^ ((c >> 4) & 15u)); }
-
+// LDS-transposed block I/O (wave_chunks.cuh explains why, and holds the index arithmetic and every kernel's hand-over plan).
 template <int CH>
 __device__ __forceinline__ void block_store_chunks(uint4* lds, uint4* gdst, const uint4 (&v)[CH], uint32_t t, uint32_t limit) {
 #pragma unroll
@@ -123,64 +118,36 @@ __device__ __forceinline__ void block_store_chunks(uint4* lds, uint4* gdst, cons
   }
   __syncthreads();
 }
-template <int CH>
-__device__ __forceinline__ void block_load_chunks(uint4* lds, const uint4* gsrc, uint4 (&v)[CH], uint32_t t, uint32_t limit) {
-#pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const uint32_t c = k * TPB + t;
-    if (c < limit) lds[chunk_swz(c)] = gsrc[c];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int c = 0; c < CH; ++c) v[c] = lds[chunk_swz(CH * t + c)];
-  __syncthreads();
-}
-// The same hand-over per WAVE: a wave parks the CH chunks of each of its 64 threads in its own LDS slice (64 * CH chunks, which are
-// also contiguous in global memory) and moves them lane-contiguously.  The LDS unit serves one wave's requests in order, so no
-// workgroup barrier is involved and the waves of a workgroup drift apart instead of meeting four times per tile: measured on the
-// leaf kernel without the leaf-level store 409 -> 339 us for 2^24 values (tools/r04/merkle_lab.hip, profiles/r04_merkle_lab.txt).
-// `limit` = valid chunks of the whole block, as above.
-#if defined(SHK_WAVE_SYNC_BLOCK)  // diagnostic builds: a workgroup barrier in its place (every thread of a workgroup reaches every hand-over)
-#define SHK_WAVE_SYNC() __syncthreads()
-#else
+// The same hand-over per WAVE, without a workgroup barrier (measured on the leaf kernel without the leaf-level store: 409 -> 339 us
+// for 2^24 values, profiles/r04_merkle_lab.txt).  H = one entry of the kernel's handover_plan; `limit` = valid chunks of the block.
 #define SHK_WAVE_SYNC()                                  \
   do {                                                   \
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
     __builtin_amdgcn_wave_barrier();                     \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
-#endif
-// LDS_CH = the chunks per thread the workgroup's LDS array was sized for: wave w owns the slice [w * 64 * LDS_CH, (w + 1) * 64 * LDS_CH)
-// in EVERY hand-over of the kernel, whatever that hand-over's own CH <= LDS_CH.  (Round 4 found the mid kernel loading through slices
-// of 512 chunks and storing through slices of 256: a wave that was already storing wrote into the slice its neighbour was still loading
-// through -- invisible while the waves of a workgroup run in step, wrong digests as soon as a second stream perturbs them;
-// tools/r04/c5_repro.py, profiles/r04_two_context_race.txt.)
-template <int CH, int LDS_CH = CH>
-__device__ __forceinline__ void wave_store_chunks(uint4* lds, uint4* gdst, const uint4 (&v)[CH], uint32_t t, uint32_t limit) {
-  static_assert(CH <= LDS_CH, "a hand-over must fit the wave's own LDS slice");
-  const uint32_t lane = t & 63u, gbase = (t >> 6) * (64 * CH), lbase = (t >> 6) * (64 * LDS_CH);
+template <class H>
+__device__ __forceinline__ void wave_store_chunks(uint4* lds, uint4* gdst, const uint4 (&v)[H::CH], uint32_t t, uint32_t limit) {
 #pragma unroll
-  for (int c = 0; c < CH; ++c) lds[lbase + chunk_swz(CH * lane + c)] = v[c];
+  for (int c = 0; c < H::CH; ++c) lds[H::own(t, c)] = v[c];
   SHK_WAVE_SYNC();
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const uint32_t c = k * 64 + lane;
-    if (gbase + c < limit) gdst[gbase + c] = lds[lbase + chunk_swz(c)];
+  for (int k = 0; k < H::CH; ++k) {
+    const uint32_t g = H::gidx(t, k);
+    if (g < limit) gdst[g] = lds[H::moved(t, k)];
   }
   SHK_WAVE_SYNC();
 }
-template <int CH, int LDS_CH = CH>
-__device__ __forceinline__ void wave_load_chunks(uint4* lds, const uint4* gsrc, uint4 (&v)[CH], uint32_t t, uint32_t limit) {
-  static_assert(CH <= LDS_CH, "a hand-over must fit the wave's own LDS slice");
-  const uint32_t lane = t & 63u, gbase = (t >> 6) * (64 * CH), lbase = (t >> 6) * (64 * LDS_CH);
+template <class H>
+__device__ __forceinline__ void wave_load_chunks(uint4* lds, const uint4* gsrc, uint4 (&v)[H::CH], uint32_t t, uint32_t limit) {
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    const uint32_t c = k * 64 + lane;
-    if (gbase + c < limit) lds[lbase + chunk_swz(c)] = gsrc[gbase + c];
+  for (int k = 0; k < H::CH; ++k) {
+    const uint32_t g = H::gidx(t, k);
+    if (g < limit) lds[H::moved(t, k)] = gsrc[g];
   }
   SHK_WAVE_SYNC();
 #pragma unroll
-  for (int c = 0; c < CH; ++c) v[c] = lds[lbase + chunk_swz(CH * lane + c)];
+  for (int c = 0; c < H::CH; ++c) v[c] = lds[H::own(t, c)];
   SHK_WAVE_SYNC();
 }
 __device__ __forceinline__ uint4 pack4(const uint32_t* w) { return make_uint4(w[0], w[1], w[2], w[3]); }
@@ -199,7 +166,7 @@ constexpr int MERKLE_ROWS = 1;
 constexpr uint64_t MERKLE_WIDE_THREADS = 1ull << 19;  // threads per launch from which the asm rounds win (measured between 2^18 and 2^20)
 template <bool RAW, bool STORE, bool WIDE>
 __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, uint64_t n, uint32_t* nodes) {
-  __shared__ uint4 lds[TPB * (STORE ? 8 : 4)];
+  __shared__ uint4 lds[TPB * (STORE ? 8 : merkle_leaves_nostore_plan::LDS_CH)];
   const uint64_t q = n >> 2;
   const uint32_t t = threadIdx.x;
   const uint64_t b = blockIdx.y;
@@ -239,7 +206,8 @@ __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, 
       if (STORE)
         block_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + (n / 2 + 2 * row0) * 8), v, t, rows_here * 4);
       else
-        wave_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + (n / 2 + 2 * row0) * 8), v, t, rows_here * 4);
+        wave_store_chunks<handover_at<0, merkle_leaves_nostore_plan>::type>(lds, reinterpret_cast<uint4*>(tree + (n / 2 + 2 * row0) * 8), v, t,
+                                                                             rows_here * 4);
     }
     if (valid) {
       b2digest d2 = b2_hash_pair<WIDE>(d0.h, d1.h);
@@ -255,23 +223,17 @@ __global__ void __launch_bounds__(TPB) merkle_leaves_kernel(const void* leaves, 
 // Wide levels: one thread reduces 4 adjacent nodes of level L to their parent pair (level L-1) and
 // grandparent (level L-2): every lane busy, three hashes per thread (two independent, one dependent).
 // grid = (ceil(2^(L-2) / 256), batch).
-#ifndef SHK_MID_WAVE
-#define SHK_MID_WAVE 1  // the LDS hand-over per wave (no workgroup barrier), as in the leaf kernel
-#endif
+// (the LDS hand-overs are per wave, no workgroup barrier, as in the leaf kernel)
 template <bool WIDE>
 __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64_t n, uint32_t L) {
-  __shared__ uint4 lds[TPB * 8];
+  __shared__ uint4 lds[TPB * merkle_mid_plan::LDS_CH];
   const uint64_t cnt = 1ull << (L - 2);  // nodes produced at level L-2, per tree
   const uint32_t t = threadIdx.x;
   const uint64_t i0 = (uint64_t)blockIdx.x * TPB, i = i0 + t;
   const uint32_t here = (uint32_t)(cnt - i0 < TPB ? cnt - i0 : TPB);
   uint32_t* tree = nodes + (uint64_t)blockIdx.y * (2 * n) * 8;
   uint4 v[8];
-#if SHK_MID_WAVE
-  wave_load_chunks<8, 8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
-#else
-  block_load_chunks<8>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
-#endif
+  wave_load_chunks<handover_at<0, merkle_mid_plan>::type>(lds, reinterpret_cast<const uint4*>(tree + ((1ull << L) + 4 * i0) * 8), v, t, here * 8);
   uint32_t w[4][8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -282,11 +244,7 @@ __global__ void __launch_bounds__(TPB) merkle_mid_kernel(uint32_t* nodes, uint64
   b2digest d1 = b2_hash_pair<WIDE>(w[2], w[3]);
   {
     uint4 u[4] = {pack4(d0.h), pack4(d0.h + 4), pack4(d1.h), pack4(d1.h + 4)};
-#if SHK_MID_WAVE
-    wave_store_chunks<4, 8>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
-#else
-    block_store_chunks<4>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
-#endif
+    wave_store_chunks<handover_at<1, merkle_mid_plan>::type>(lds, reinterpret_cast<uint4*>(tree + ((1ull << (L - 1)) + 2 * i0) * 8), u, t, here * 4);
   }
   if (i >= cnt) return;
   b2digest d2 = b2_hash_pair<WIDE>(d0.h, d1.h);
@@ -605,10 +563,7 @@ hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint3
 }
 // the serial levels L .. 1 -> 0 of a tree: as few launches as 8 levels per launch allow, the levels dealt evenly
 // (15 = 8 + 7, 13 = 7 + 6, 11 = 6 + 5)
-#ifndef SHK_SERIAL_TREE_LOG
-#define SHK_SERIAL_TREE_LOG 15
-#endif
-constexpr uint64_t MERKLE_SERIAL_MAX_LEAVES = 1ull << SHK_SERIAL_TREE_LOG;  // trees (times batch) up to this many leaves start in serial form
+constexpr uint64_t MERKLE_SERIAL_MAX_LEAVES = 1ull << 15;  // trees (times batch) up to this many leaves start in serial form
 static hipError_t merkle_serial_levels(int L, uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st) {
   while (L > 0) {
     const int launches = (L + 7) / 8, levels = (L + launches - 1) / launches;
@@ -663,9 +618,7 @@ hipError_t shk_merkelize(const void* d_leaves, bool raw_leaves, uint64_t n, uint
   return shk_merkle_upper_levels(n, batch, d_nodes, st);
 }
 // levels log2(n)-2 .. 0 from the nodes the leaf kernels wrote (node layout of merkle_tree.py:36-56)
-#ifndef SHK_MID_MIN_LOG
-#define SHK_MID_MIN_LOG 15  // a level pair goes to the (throughput-form) mid kernel while it has at least 2^this threads
-#endif
+constexpr int MID_MIN_LOG = 15;  // a level pair goes to the (throughput-form) mid kernel while it has at least 2^this threads
 hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes, hipStream_t st) {
   hipError_t e = hipSuccess;
   uint32_t logn = 0;
@@ -674,7 +627,7 @@ hipError_t shk_merkle_upper_levels(uint64_t n, uint32_t batch, uint32_t* d_nodes
   // wide levels: two levels per launch at full lane efficiency, while a level still fills the chip
   // (the threshold is flat: 2^15 .. 2^19 threads measure within +-1.5 % of each other on 2^20 .. 2^24 leaves and on the FRI
   // commits, profiles/r04_merkle_lab.txt)
-  while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << SHK_MID_MIN_LOG)) {
+  while (L >= 2 && ((1ull << (L - 2)) * batch) >= (1ull << MID_MIN_LOG)) {
     if (((1ull << (L - 2)) * batch) >= MERKLE_WIDE_THREADS / 2)
       hipLaunchKernelGGL(merkle_mid_kernel<true>, dim3(grid_for(1ull << (L - 2)), batch), dim3(TPB), 0, st, d_nodes, n, (uint32_t)L);
     else

@@ -11,7 +11,7 @@
 //                                  long transform 11, ntt.hip); setting it switches that first-pass rule off
 //   STARKHIP_TILE_LOG_BIG=10|11|12 the same for the radix 2^9 .. 2^11 passes (default 11)
 //   STARKHIP_TILE_LOGS="11,10,10"  per pass 0, 1, 2, ... (9..12; 0 = the rules above)
-//   STARKHIP_XCD_SWZ=0|1|2|3       workgroup -> tile mapping over the 8 XCDs (ntt_kernels.cuh:shk_launch_tile_kernel)
+//   STARKHIP_XCD_SWZ=0|1|2         workgroup -> tile mapping over the 8 XCDs (ntt_kernels.cuh:shk_launch_tile_kernel)
 //   STARKHIP_TW2_MAX_LOG=k         row-major inter-pass twiddle tables up to 2^k entries (default 24), else the power-table lookup
 //   STARKHIP_PLAN_CACHE_MB=m       initial plan-cache budget of a context
 //   STARKHIP_NTT_NARROW_TILES=k    passes of at most k 1024-element tiles (and radix <= 2^10) run in the one-butterfly-per-thread form
@@ -61,7 +61,7 @@ inline void parse(ShkKnobs* k) {
   parse_list(getenv("STARKHIP_TILE_LOGS"), k->tile_logs, 8, 9, 12, 0);
   if (const char* e = getenv("STARKHIP_XCD_SWZ")) {
     const int v = atoi(e);
-    k->xcd_swz = (v < 0 || v > 3) ? 0 : v;
+    k->xcd_swz = (v < 0 || v > 2) ? 0 : v;
   }
   if (const char* e = getenv("STARKHIP_TW2_MAX_LOG")) {
     const int v = atoi(e);

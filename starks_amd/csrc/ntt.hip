@@ -13,7 +13,7 @@ hipError_t launch_tile(const NttPassArgs& a, hipStream_t st) {
   constexpr int LOG_T = TILE_LOG - LOG_R;
   static std::atomic<uint64_t> attr_done{0};
   return shk_launch_tile_kernel(ntt_pass_kernel<LOG_R, LOG_T, LAST>, attr_done, LOG_T, 1u << (TILE_LOG - 2), (size_t)32 << TILE_LOG,
-                                LAST, a, st);
+                                a, st);
 }
 
 // narrow launches (ntt_kernels.cuh): at most kn.narrow_tiles tiles of 1024 elements, radix <= 2^10

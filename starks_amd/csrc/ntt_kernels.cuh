@@ -23,15 +23,6 @@
 #include "knobs.hpp"
 
 
-// A/B knobs of round 4: non-temporal loads in the first pass of the long transforms (the 2048-element tiles of
-// radix 2^8: ntt_pass_kernel<8, 3, false>), whose 512 MiB row table (SHK_NT_TW2) and whose own elements (SHK_NT_ELEM) are read once.
-#ifndef SHK_NT_TW2
-#define SHK_NT_TW2 0
-#endif
-#ifndef SHK_NT_ELEM
-#define SHK_NT_ELEM 0
-#endif
-
 // LDS image of a tile: 32-byte elements, 8 to a 256-byte bank row; the slot inside the row is XOR-ed with
 // the higher index bits so that any power-of-two stride between lanes spreads over all 8 slots.
 __host__ __device__ constexpr uint32_t lds_slot(uint32_t e) {
@@ -275,10 +266,7 @@ __device__ __forceinline__ void ntt_group(const NttPassArgs& a, uint4* lds, Tile
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
         const uint32_t i = th.ibase | ((uint32_t)h << beta);
-        if constexpr (SHK_NT_ELEM && LOG_R == 8 && LOG_T == 3 && !LAST)
-          th.x[h] = fp_load_nt(a.src + th.gbase + ((uint64_t)i << a.log_S));
-        else
-          th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
+        th.x[h] = LAST ? fp_load(a.src + th.gbase + i) : fp_load(a.src + th.gbase + ((uint64_t)i << a.log_S));
       }
     }
   } else {
@@ -340,15 +328,6 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a) {
   if (a.xcd_per) {
     tile = (uint64_t)(blockIdx.x & 7u) * a.xcd_per + (blockIdx.x >> 3);
     if ((tile << LOG_T) >= a.total) return;  // grid padding (whole workgroup, before any barrier)
-    if (!LAST && a.sharers) {
-      // order: (line group of adjacent column tiles, sharer, tile inside the line group) -- the tiles that share 128-byte
-      // lines (T < 4) stay adjacent, then come the other sharers of the same twiddle rows
-      constexpr int GRP = LOG_T < 2 ? 2 - LOG_T : 0;
-      const uint32_t tl = (uint32_t)tile;
-      const uint32_t low = tl & ((1u << GRP) - 1u), rest = tl >> GRP;
-      const uint32_t hi = rest / a.sharers, v = rest - hi * a.sharers;
-      tile = ((uint64_t)v << (a.log_S - LOG_T)) + ((hi << GRP) | low);
-    }
   }
   const uint64_t tile0 = tile << LOG_T;
   TileThread th;
@@ -362,7 +341,6 @@ __device__ __forceinline__ void ntt_pass_body(const NttPassArgs& a) {
   auto itw_load = [&](int h) {
     const uint32_t i = tile_ibase<LOG_R, LOG_T, G - 1>(tid) | (uint32_t)h;  // the last group's element index (beta = 0)
     const uint32_t k = __brev(i) >> (32 - LOG_R);
-    if constexpr (SHK_NT_TW2 && LOG_R == 8 && LOG_T == 3 && !LAST) return fp_load_nt(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
     return fp_load(a.tw2 + ((uint64_t)k << a.log_S) + th.j2);
   };
   auto itw_request = [&]() {
@@ -530,44 +508,29 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 1)) ntt_narrow_pass_kern
 // are dealt to the 8 XCDs round-robin, so neighbours would sit behind different L2s and every line would be fetched (or
 // written back partially) twice.  Default (1): such launches map adjacent tiles to the same XCD (measured on the T = 1
 // variant: 8.6 -> 10.2 G elements/s).  STARKHIP_XCD_SWZ (knobs.hpp): 0 = never, 2 = every tile pass (measured level for
-// T >= 4), 3 = as 1 plus the sharer-fastest order below.
+// T >= 4).
 
 // attr_done: one bit per device ordinal, per kernel instantiation (contexts on several devices, and on several host threads,
 // share the launcher)
 inline hipError_t shk_launch_tile_kernel(void (*k)(NttPassArgs), std::atomic<uint64_t>& attr_done, int log_t, unsigned threads,
-                                         size_t lds_bytes, bool last, const NttPassArgs& a, hipStream_t st) {
+                                         size_t lds_bytes, const NttPassArgs& a, hipStream_t st) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;
   const uint64_t bit = 1ull << (dev & 63);
   if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-#if defined(SHK_LDS_PAD_KIB)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_bytes + ((size_t)SHK_LDS_PAD_KIB << 10)));
-#else
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-#endif
     if (e != hipSuccess) return e;
     attr_done.fetch_or(bit, std::memory_order_release);
   }
-#if defined(SHK_LDS_PAD_KIB)  // diagnostic builds: a larger LDS allocation = fewer resident workgroups (occupancy experiments)
-  lds_bytes += (size_t)SHK_LDS_PAD_KIB << 10;
-#endif
   const uint64_t tiles = (a.total + ((1ull << log_t) - 1)) >> log_t;
   if (tiles == 0) return hipSuccess;
   if (tiles > 0x7ffffff0ull) return hipErrorInvalidValue;
   NttPassArgs b = a;
   uint64_t grid = tiles;
-  // column passes whose twiddle rows (tw2) are shared by several vectors / prefix blocks: sharer-fastest order, XCD-local.
-  // Opt-in only (STARKHIP_XCD_SWZ=3): it removes the per-vector re-fetch of the rows (2 * FETCH_SIZE of the 2^20 x 8 column
-  // pass 540 -> 325 MB) but measured 3-8 % SLOWER -- the sharers sit 2^k bytes apart, so the concurrently running tiles
-  // all map to the same memory channels.
-  const uint64_t sharers = last ? 0 : (a.total >> a.log_S);
   const int swz = shk_knobs().xcd_swz;
-  const bool share = !last && a.tw2 && sharers >= 2 && sharers <= 0xffffffffull && a.log_S >= (uint32_t)log_t + 2 &&
-                     tiles <= 0xffffffffull && swz == 3;
-  if (swz && (swz == 2 || log_t < 2 || share) && tiles >= 64) {
+  if (swz && (swz == 2 || log_t < 2) && tiles >= 64) {
     b.xcd_per = (uint32_t)((tiles + 7) / 8);
-    b.sharers = share ? (uint32_t)sharers : 0;
     grid = 8ull * b.xcd_per;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds_bytes, st, b);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Digests of NTTs too long for the pure-Python reference (2^19 and 2^21 ... 2^24 points; the reference needs ~25 min and
+"""Digests of NTTs too long for the pure-Python reference (2^17 dense, 2^19 and 2^21 ... 2^24 points; the reference needs ~25 min and
 several GB for 2^24), computed with the C oracle (oracle/oracle.c: the reference's recursive
 radix-2 algorithm, fft.py:287-331).  The oracle itself is pinned to the live reference up to 2^20 points by
 tests/golden/generate.py + tests/test_coracle.py, so these digests are reference-independent pins for the sizes the
@@ -7,13 +7,23 @@ reference cannot reach (BASELINE configs[3]).
 
     python3 tests/golden/generate_large.py          # writes tests/golden/ntt_large.json  (about 4 min, 4 GB)
     python3 tests/golden/generate_large.py --missing  # keeps the cases already in the file, adds the sizes it lacks
+    python3 tests/golden/generate_large.py --fri      # writes tests/golden/fri_large.json (about 3 min, 3 GB): below
 
-2^19 is the domain of config 5's proofs (plan (9, 10)), 2^21 the first three-pass plan, 2^23 the domain of the metric's
+2^17 is the domain of config 3's commit, whose default plan (9, 8) the reference-generated fixtures reach only through the
+sparse first pass (a dense vector of that length: here).  2^19 is the domain of config 5's proofs (plan (9, 10)), 2^21 the first three-pass plan, 2^23 the domain of the metric's
 2^20-step FRI commit (the plan with the 256 MiB row table): each of these plan shapes gets its own digest.
 
 Input: x_i = BLAKE2s(seed_le64 || i_le64) mod p with seed 0x5eed; w = 7^((p-1)/n).
 Recorded: SHA-256 of the forward transform's wire bytes, of the inverse transform of the INPUT (inv(x), not the round
-trip), and the first two output elements of each."""
+trip), and the first two output elements of each.
+
+--fri: the FRI commits bench.py times (the metric's second half, "FRI-commit ms for 2^20 trace", and the 2^14 / 2^16-step ones
+beside it): coefficients c_i = BLAKE2s(seed_le64 || i_le64) mod p, seed 0xF51, i < steps (a degree < steps polynomial, as
+bench.py:extras fills it), 8x extension, w = 7^((p-1)/(8 steps)), maxdeg_plus_1 = steps, exclude_multiples_of = 8, 40 samples:
+SHA-256 of the flat proof oracle/oracle.c:fri_rec writes (the reference's commit loop, fri.py:189-266, with its iNTT -> NTT per
+round and its Lagrange fold), its length, the first round's root2 and the final layer's first value.  The reference itself cannot
+reach these sizes (2^14 steps take it 20 s, 2^20 would take hours); the C oracle is pinned to it on the 2^14-step MiMC commit and
+seven smaller ones (tests/golden/fri.json, tests/test_coracle.py)."""
 import hashlib
 import json
 import os
@@ -29,10 +39,45 @@ P = 2**256 - 2**32 * 351 + 1
 SEED = 0x5eed
 
 
-LOGNS = (19, 21, 22, 23, 24)
+LOGNS = (17, 19, 21, 22, 23, 24)
+FRI_LOGSTEPS = (14, 16, 20)
+FRI_SEED = 0xF51
+
+
+def fri_main():
+    out = os.path.join(HERE, "fri_large.json")
+    cases = []
+    if "--missing" in sys.argv[1:] and os.path.exists(out):
+        with open(out) as fh:
+            cases = json.load(fh)["cases"]
+    have = {c["logsteps"] for c in cases}
+    for logsteps in FRI_LOGSTEPS:
+        if logsteps in have:
+            continue
+        steps, ext = 1 << logsteps, 8
+        n = steps * ext
+        t0 = time.time()
+        coeffs = b"".join((int.from_bytes(hashlib.blake2s(struct.pack("<QQ", FRI_SEED, i)).digest(), "big") % P).to_bytes(32, "big")
+                          for i in range(steps))
+        g2 = pow(7, (P - 1) // n, P)
+        flat = coracle.fri_prove_flat(coeffs, g2, steps, ext, 40, n=n)
+        case = {"logsteps": logsteps, "steps": steps, "ext": ext, "domain": n, "seed": FRI_SEED, "samples": 40,
+                "exclude_multiples_of": ext, "maxdeg_plus_1": steps, "w": "%064x" % g2,
+                "coeffs_sha256": hashlib.sha256(coeffs).hexdigest(), "proof_bytes": len(flat),
+                "proof_sha256": hashlib.sha256(flat).hexdigest(), "first_root2": flat[:32].hex(),
+                "final_layer_first": flat[len(flat) - 32 * 128:len(flat) - 32 * 127].hex(),
+                "oracle_seconds": round(time.time() - t0, 1)}
+        print(case, flush=True)
+        cases.append(case)
+    cases.sort(key=lambda c: c["logsteps"])
+    with open(out, "w") as fh:
+        json.dump({"generator": "tests/golden/generate_large.py --fri (oracle/oracle.c:fri_rec, pinned to the reference by fri.json)",
+                   "cases": cases}, fh, indent=1)
 
 
 def main():
+    if "--fri" in sys.argv[1:]:
+        return fri_main()
     out = os.path.join(HERE, "ntt_large.json")
     cases = []
     if "--missing" in sys.argv[1:] and os.path.exists(out):

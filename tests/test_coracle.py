@@ -155,6 +155,20 @@ def test_fri_flat_golden(rec):
     assert flat[off:] == b"".join(bytes.fromhex(v) for v in rec["final_values"])
 
 
+@pytest.mark.parametrize("logsteps", [14, 16])
+def test_fri_large_fixture_is_what_the_oracle_writes(logsteps):
+    """tests/golden/fri_large.json (the commits bench.py times; the GPU suite compares the library with it) regenerates from the
+    oracle: the 2^14- and 2^16-step cases here (0.5 s and 2 s), the 2^20-step one (74 s) only in generate_large.py --fri."""
+    import struct
+    c = [c for c in load_golden("fri_large.json")["cases"] if c["logsteps"] == logsteps][0]
+    coeffs = b"".join((int.from_bytes(hashlib.blake2s(struct.pack("<QQ", c["seed"], i)).digest(), "big") % P).to_bytes(32, "big")
+                      for i in range(c["steps"]))
+    assert hashlib.sha256(coeffs).hexdigest() == c["coeffs_sha256"]
+    flat = co.fri_prove_flat(coeffs, int(c["w"], 16), c["maxdeg_plus_1"], c["exclude_multiples_of"], c["samples"], n=c["domain"])
+    assert len(flat) == c["proof_bytes"] and hashlib.sha256(flat).hexdigest() == c["proof_sha256"]
+    assert flat[:32].hex() == c["first_root2"]
+
+
 def test_sanitized_build():
     """-fsanitize=address,undefined build of the oracle runs the FRI path clean."""
     so = os.path.join(ROOT, "oracle", "liboracle_asan.so")

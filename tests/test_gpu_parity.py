@@ -84,7 +84,7 @@ def test_ntt_every_size_vs_oracle(sa, oracle, logn):
     n = 1 << logn
     w = root_of(n)
     rng = random.Random(logn)
-    if logn <= 16:
+    if True:  # every size dense (2^17 .. 2^20 as well: the scalar oracle takes 0.2 .. 2 s per transform there)
         vals = [rng.randrange(2**256) for _ in range(n)]  # unreduced inputs allowed (modp.py:33-34)
         vals[0] = 2**256 - 1
         if n > 1:
@@ -94,8 +94,8 @@ def test_ntt_every_size_vs_oracle(sa, oracle, logn):
         exp_i = oracle.c.fft_bytes(data, n, w, inverse=True)
         assert sa.fft.ntt_bytes(data, n, w) == exp_f
         assert sa.fft.ntt_bytes(data, n, w, inverse=True) == exp_i
-    else:
-        # too slow for the scalar oracle in a unit test: round trip + linearity + Parseval-like point checks
+    if logn > 16:
+        # on top of the dense comparison: round trip + point checks on a structured input (8 values repeated: a sparse spectrum)
         data = bytes(rng.getrandbits(8) for _ in range(32 * 8)) * (n // 8)
         fwd = sa.fft.ntt_bytes(data, n, w)
         assert sa.fft.ntt_bytes(fwd, n, w, inverse=True) == wire(v % P for v in unwire(data))
@@ -401,6 +401,41 @@ def test_full_size_fri_prove_then_verify(sa, logsteps):
         sa.fri.verify_low_degree_proof(bad, mroot, g2, steps, ext)
     for d in (dc, dv, dt, dp):
         assert L.sh_dev_free(ctx, d) == 0
+
+
+@pytest.mark.parametrize("logsteps", [14, 16, 20])
+def test_fri_commits_of_the_metric_vs_oracle_fixture(sa, logsteps):
+    """The commits bench.py times -- 2^14 (config 3's size), 2^16 (config 5's) and 2^20 steps ("FRI-commit ms for 2^20 trace") on the
+    seeded degree < steps polynomial -- byte for byte against the flat proofs oracle/oracle.c:fri_rec wrote (the reference's loop,
+    fri.py:189-266, with its per-round iNTT -> NTT and Lagrange fold; tests/golden/fri_large.json, generate_large.py --fri), from the
+    coefficients a prover holds and from the zero-padded vector."""
+    import ctypes
+    c = [c for c in load_golden("fri_large.json")["cases"] if c["logsteps"] == logsteps][0]
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    steps, ext = c["steps"], c["ext"]
+    n = steps * ext
+    w = root_of(n).to_bytes(32, "big")
+    assert w.hex() == c["w"] and n == c["domain"]
+    plen = int(L.sh_fri_proof_len(n, c["maxdeg_plus_1"], c["samples"]))
+    assert plen == c["proof_bytes"]
+    dc, dp = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dc)) == 0 and L.sh_dev_alloc(ctx, plen, ctypes.byref(dp)) == 0
+    assert L.sh_dev_fill_seeded(ctx, dc, steps, c["seed"]) == 0
+    assert L.sh_dev_upload(ctx, bytes(32 * (n - steps)), ctypes.c_void_p(dc.value + 32 * steps), 32 * (n - steps)) == 0
+    head = ctypes.create_string_buffer(32 * steps)
+    assert L.sh_dev_to_wire(ctx, dc, head, steps) == 0
+    assert hashlib.sha256(head.raw).hexdigest() == c["coeffs_sha256"]  # the input is the fixture's input
+    flat = ctypes.create_string_buffer(plen)
+    for dense in (False, True):
+        if dense:
+            assert L.sh_dev_fri_prove(ctx, dc, n, w, c["maxdeg_plus_1"], c["exclude_multiples_of"], c["samples"], 1, dp) == 0
+        else:
+            assert L.sh_dev_fri_prove_coeffs(ctx, dc, steps, n, w, c["maxdeg_plus_1"], c["exclude_multiples_of"], c["samples"], 1, dp) == 0
+        assert L.sh_dev_download(ctx, dp, flat, plen) == 0
+        assert flat.raw[:32].hex() == c["first_root2"], (logsteps, dense)
+        assert flat.raw[plen - 32 * 128:plen - 32 * 127].hex() == c["final_layer_first"], (logsteps, dense)
+        assert hashlib.sha256(flat.raw).hexdigest() == c["proof_sha256"], (logsteps, dense)
+    assert L.sh_dev_free(ctx, dc) == 0 and L.sh_dev_free(ctx, dp) == 0
 
 
 def test_batched_mimc_proofs_config5_shape(sa, oracle):
@@ -875,9 +910,9 @@ def test_full_size_merkle_2_24_branches_verify(sa):
 
 
 # ---- round 2: reference-independent pins for config 4, config 5 at its size, the new ABI entries -------------------------
-@pytest.mark.parametrize("logn", [19, 21, 22, 23, 24])
+@pytest.mark.parametrize("logn", [17, 19, 21, 22, 23, 24])
 def test_ntt_large_digests_vs_oracle_fixture(sa, logn):
-    """Config 4 (2^24), 2^22 and the three plan shapes no reference digest reaches -- 2^19 (config 5's domain, plan (9, 10)),
+    """Config 4 (2^24), 2^22 and the plan shapes no reference digest reaches densely -- 2^17 (config 3's domain, plan (9, 8)), 2^19 (config 5's domain, plan (9, 10)),
     2^21 (the first three-pass plan) and 2^23 (the domain of the metric's 2^20-step FRI commit, 256 MiB row table): forward and
     inverse transforms of the seeded vector against the digests the C oracle produced (tests/golden/ntt_large.json; the
     oracle is pinned to the live reference up to 2^20)."""
@@ -1117,11 +1152,10 @@ def test_bench_rccl_collectives_with_one_rank(sa, workload):
     {"STARKHIP_NTT_RADICES": "10,10", "STARKHIP_TILE_LOG_BIG": "12", "STARKHIP_XCD_SWZ": "0"},  # 4096-element tiles
     {"STARKHIP_NTT_RADICES": "11,9", "STARKHIP_TILE_LOG_BIG": "11"},  # radix 2^11: one column / one row per tile
     {"STARKHIP_NTT_RADICES": "6,6,4", "STARKHIP_TILE_LOG": "11"},     # 2^16 in three passes, 2048-element tiles
-    {"STARKHIP_XCD_SWZ": "3"},                                        # column tiles in sharer-fastest order
     {"STARKHIP_TILE_LOGS": "11,9,10", "STARKHIP_TW2_MAX_LOG": "20"},  # a tile size per pass; small row tables (lookup fallback)
     {"STARKHIP_NTT_NARROW_TILES": "100000000"},                       # every pass of radix <= 2^10 in the one-butterfly-per-thread form
     {"STARKHIP_NTT_NARROW_TILES": "100000000", "STARKHIP_NTT_RADICES": "5,5,4,3", "STARKHIP_TW2_MAX_LOG": "12"},  # ... four passes of 2^17, lookups
-], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "sharer_order", "per_pass_tiles", "narrow_everywhere", "narrow_5-5-4-3"])
+], ids=["7-7-6_swz2", "10-10_tile4096", "11-9", "6-6-4_tile2048", "per_pass_tiles", "narrow_everywhere", "narrow_5-5-4-3"])
 def test_alternate_ntt_plans_parity(sa, env):
     """Every decomposition the plan / tile knobs can select gives the same bytes: the NTT golden vectors (reference digests to
     2^20), every size against the oracle and the 2^22 / 2^24 digests, in a child process with the knobs set.  (The plan / tile

@@ -43,7 +43,7 @@ while time.time() - t0 < budget:
         continue
     rad = parts(logn, k, rng=rng)
     env = dict(os.environ, STARKHIP_NTT_RADICES=",".join(map(str, rad)), STARKHIP_TILE_LOG=str(rng.choice([9, 10, 11])),
-               STARKHIP_TILE_LOG_BIG=str(rng.choice([10, 11, 12])), STARKHIP_XCD_SWZ=str(rng.choice([0, 1, 2, 3])),
+               STARKHIP_TILE_LOG_BIG=str(rng.choice([10, 11, 12])), STARKHIP_XCD_SWZ=str(rng.choice([0, 1, 2])),
                # the narrow-launch form: never / the default threshold / every launch
                STARKHIP_NTT_NARROW_TILES=rng.choice(["0", "0", "256", "100000000"]))
     out = subprocess.run([sys.executable, "-c", CHILD, str(rng.randrange(1 << 30)), str(logn), per], env=env, capture_output=True, text=True, timeout=300)
