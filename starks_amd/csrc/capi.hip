@@ -114,7 +114,7 @@ struct sh_ctx {
   bool pin_busy[2] = {false, false};
   // STARK prover state: 1/((x_i - 1)(x_i - x_last)) and 1/(omega^j - 1) per (steps, ext); the step-polynomial terms last
   // uploaded (and their partial derivatives); the constraint flag
-  std::map<std::pair<uint64_t, uint32_t>, void*> inv_z2;
+  std::map<std::pair<uint64_t, uint32_t>, void*> inv_z2;  // the three domain tables of (steps, ext): [3][n] (shk_stark_domain_tables)
   std::map<std::pair<uint64_t, uint32_t>, void*> inv_omega;
   std::vector<uint8_t> terms_key;
   void* terms_dev = nullptr;   // [terms][derivative terms]: see TermLayout
@@ -836,32 +836,14 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   SH_TRY(ws_get(c, sh_ctx::WS_ST_B, cols * n * sizeof(fp), &bw));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_Q, cols * steps * sizeof(fp), &qv));
   SH_TRY(ws_get(c, sh_ctx::WS_ST_MTREE, (size_t)batch * 2 * n * 32, &mt));
-  const size_t iab_bytes = cols * 2 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp2);  // scalars as (s, s 2^128) pairs
+  const size_t iab_bytes = cols * 3 * sizeof(fp), scal_bytes = cols * 3 * sizeof(fp2);  // scalars as (s, s 2^128) pairs
   SH_TRY(ws_get(c, sh_ctx::WS_ST_SMALL, iab_bytes + scal_bytes + (size_t)batch * samples * 4, &small));
   fp* iab = reinterpret_cast<fp*>(small);
   fp* scal = reinterpret_cast<fp*>(reinterpret_cast<uint8_t*>(small) + iab_bytes);
   uint32_t* ys = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(small) + iab_bytes + scal_bytes);
   SH_TRY(bad_flags(c, batch));
-  // cached inverses: 1 / ((x_i - 1)(x_i - x_last)) over the domain, 1 / (omega^j - 1) for the ext-th roots of unity
-  // omega^j = x^steps
-  fp* inv_z2 = nullptr;
-  {
-    const auto key = std::make_pair(steps, ext);
-    auto it = c->inv_z2.find(key);
-    if (it == c->inv_z2.end()) {
-      void* t = nullptr;
-      HIP_TRY(c, hipMalloc(&t, n * sizeof(fp)));
-      inv_z2 = reinterpret_cast<fp*>(t);
-      const hipError_t e = shk_stark_inv_z2(inv_z2, n, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, x_last, c->stream);
-      if (e != hipSuccess) {  // never cache a table whose fill did not launch
-        (void)hipFree(t);
-        HIP_TRY(c, e);
-      }
-      c->inv_z2[key] = t;
-    } else {
-      inv_z2 = reinterpret_cast<fp*>(it->second);
-    }
-  }
+  // cached per (steps, ext): 1 / (omega^j - 1) for the ext-th roots of unity omega^j = x^steps, and the domain tables
+  // 1 / ((x_i - 1)(x_i - x_last)), x_i, (x_i - x_last) / (x_i^steps - 1)   (3 n elements, shared by every proof)
   fp* inv_omega = nullptr;
   {
     const auto key = std::make_pair(steps, ext);
@@ -887,6 +869,25 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
       inv_omega = reinterpret_cast<fp*>(it->second);
     }
   }
+  fp* inv_z2 = nullptr;
+  {
+    const auto key = std::make_pair(steps, ext);
+    auto it = c->inv_z2.find(key);
+    if (it == c->inv_z2.end()) {
+      void* t = nullptr;
+      HIP_TRY(c, hipMalloc(&t, 3 * n * sizeof(fp)));
+      inv_z2 = reinterpret_cast<fp*>(t);
+      const hipError_t e = shk_stark_domain_tables(inv_z2, n, ext, fwd_n->base.lo, fwd_n->base.hi, fwd_n->base.lb, x_last, inv_omega,
+                                                   c->stream);
+      if (e != hipSuccess) {  // never cache a table whose fill did not launch
+        (void)hipFree(t);
+        HIP_TRY(c, e);
+      }
+      c->inv_z2[key] = t;
+    } else {
+      inv_z2 = reinterpret_cast<fp*>(it->second);
+    }
+  }
   const uint8_t* tb = reinterpret_cast<const uint8_t*>(c->terms_dev);
   StarkArgs a;
   memset(&a, 0, sizeof a);
@@ -905,6 +906,8 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   a.tw_hi = fwd_n->base.hi;
   a.tw_lb = fwd_n->base.lb;
   a.inv_z2 = inv_z2;
+  a.xpow = inv_z2 + n;
+  a.fz = inv_z2 + 2 * n;
   a.inv_omega = inv_omega;
   a.x_last = x_last;
   a.g1 = g1;
@@ -930,11 +933,10 @@ int run_stark(sh_ctx* c, fp* d_wit, const fp* d_inputs, uint64_t steps, uint32_t
   // Q = X P'(X) on the trace points, for the quotients' values there
   HIP_TRY(c, shk_stark_qprep(Q, Q, steps, cols, c->stream));
   SH_TRY(run_ntt(c, fwd_s, Q, Q, (uint32_t)cols));
-  // D = C / Z and B = (P - I) / Z2 (stark.py:38-104), evaluated on the whole domain
-  HIP_TRY(c, shk_stark_quotients(a, c->stream));
+  // D = C / Z and B = (P - I) / Z2 (stark.py:38-104), evaluated on the whole domain, and
   // mtree = merkelize_polynomial_evaluations(width, P + D + B evaluations) (stark.py:257)
   uint32_t* mtree = reinterpret_cast<uint32_t*>(mt);
-  HIP_TRY(c, shk_stark_merkelize(a, mtree, c->stream));
+  HIP_TRY(c, shk_stark_quotients_and_merkelize(a, mtree, c->stream));
   // l = pseudorandom linear combination keyed by mtree's root (stark.py:128-177, 259-263), on evaluations
   FriBuffers fb;
   SH_TRY(fri_buffers(c, n, batch, samples, &fb));

@@ -120,7 +120,7 @@ struct StarkArgs {
   const fp* q_evals;  // [batch * width][steps]  Q_c = X P_c'(X) on G1
   const fp* wit;      // [batch * width][steps]  the witness itself = the trace polynomials on G1 (read contiguously by the
                       // trace-point kernel instead of every ext-th entry of p_evals)
-  const fp* iab;      // [batch * width][2]  boundary interpolant a + b X
+  const fp* iab;      // [batch * width][3]  boundary interpolant a + b X: a, b, b 2^128 (b as an fp_mul2 pair)
   uint64_t n;         // precision = steps * ext
   uint64_t steps;
   uint32_t ext;
@@ -129,7 +129,11 @@ struct StarkArgs {
   const fp* tw_lo;    // powers of G2: G2^e = lo[e & mask] (* hi[e >> lb] when hi)
   const fp* tw_hi;
   uint32_t tw_lb;
+  // per-(steps, ext) tables over the domain (cached by the context, shared by every proof of every batch):
   const fp* inv_z2;     // [n]   1 / ((x_i - 1)(x_i - x_last)), 0 at the two roots
+  const fp* xpow;       // [n]   x_i = G2^i
+  const fp* fz;         // [n]   (x_i - x_last) / (x_i^steps - 1) = 1 / Z(x_i), 0 on the trace points (i % ext == 0)
+                        // (as fp_mul2 pairs the two factor tables measured 1 % slower: 64 B more table traffic per point)
   const fp* inv_omega;  // [ext] 1 / (omega^j - 1), omega = G2^steps, entry 0 = 0
   fp x_last;          // G2^((steps - 1) ext)  (stark.py:212)
   fp g1;              // G2^ext = 1 / x_last
@@ -149,10 +153,12 @@ struct StarkArgs {
 hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, uint32_t cols, const fp& inv_last_m1, fp* iab,
                             hipStream_t st);
 hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols, hipStream_t st);
-hipError_t shk_stark_inv_z2(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, const fp& x_last,
-                            hipStream_t st);
-hipError_t shk_stark_quotients(const StarkArgs& a, hipStream_t st);
-hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st);
+// the three domain tables, out = [3][n]: inv_z2, xpow, fz (inv_omega = the [ext] table, already on the device)
+hipError_t shk_stark_domain_tables(fp* out, uint64_t n, uint32_t ext, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, const fp& x_last,
+                                   const fp* inv_omega, hipStream_t st);
+// D = C / Z and B = (P - I) / Z2 on the whole domain and the packed-leaf Merkle tree over (P, D, B), in one pass over the domain (the
+// quotients are hashed where they are computed)
+hipError_t shk_stark_quotients_and_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st);
 hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
                              fp* d_scal, hipStream_t st);
 // l = the Fiat-Shamir linear combination of P, D, B (scalars as (s, s 2^128) pairs) and the Merkle tree of l

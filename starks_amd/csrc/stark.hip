@@ -55,9 +55,12 @@ __global__ void __launch_bounds__(TPB) stark_interp_kernel(const fp* trace, cons
   if (c >= cols) return;
   const fp in = fp_load(inputs + c);
   const fp out = fp_load(trace + (uint64_t)c * steps + (steps - 1));
-  const fp b = fp_mul(fp_sub(out, in), inv_last_m1);
-  fp_store(iab + 2 * c, fp_sub(in, b));
-  fp_store(iab + 2 * c + 1, b);
+  const fp b = fp_canon(fp_mul(fp_sub(out, in), inv_last_m1));
+  fp two128 = fp_zero();
+  two128.v[4] = 1;
+  fp_store(iab + 3 * c, fp_sub(in, b));
+  fp_store(iab + 3 * c + 1, b);
+  fp_store(iab + 3 * c + 2, fp_mul(b, two128));  // the slope as an fp_mul2 pair
 }
 
 // ---- step polynomials: sparse terms coef * prod_v X_v^exps[v] (multivariate_polynomial.py:329-338) -----------
@@ -92,45 +95,17 @@ __global__ void __launch_bounds__(TPB) stark_qprep_kernel(const fp* pcoef, fp* q
   fp_store(q + g, fp_mul(fp_load(pcoef + g), fp_from_u32((uint32_t)k)));
 }
 
-// U[i] = 1 / ((x_i - 1)(x_i - r)), 0 at x = 1 and x = r.  Once per (steps, ext) (cached by the context).
-__global__ void __launch_bounds__(TPB) stark_inv_z2_kernel(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi,
-                                                           uint32_t tw_lb, fp x_last) {
+// The domain tables, once per (steps, ext) (cached by the context): out[0][i] = 1 / ((x_i - 1)(x_i - r)) (0 at x = 1 and x = r),
+// out[1][i] = x_i, out[2][i] = (x_i - r) / (x_i^s - 1) (0 on the trace points).
+__global__ void __launch_bounds__(TPB) stark_domain_tables_kernel(fp* out, uint64_t n, uint32_t ext, const fp* tw_lo, const fp* tw_hi,
+                                                                  uint32_t tw_lb, fp x_last, const fp* inv_omega) {
   const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   if (i >= n) return;
   const fp x = pow_lookup(tw_lo, tw_hi, tw_lb, i);
   fp_store(out + i, fp_inv(fp_mul(fp_sub(x, fp_one()), fp_sub(x, x_last))));  // fp_inv(0) = 0
-}
-
-// ---- D and B off the trace points; B on the trace points other than 1 and x_last ------------------------------
-template <int W>
-__global__ void __launch_bounds__(TPB) stark_quotients_kernel(StarkArgs a) {
-  const uint64_t N = a.n;
-  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
-  if (g >= N * a.batch) return;
-  const uint64_t b = g / N, i = g - b * N;
-  const uint32_t j = (uint32_t)i & (a.ext - 1);
-  const uint64_t inext = (i + a.ext) & (N - 1);
-  if (j == 0 && (i == 0 || inext == 0)) return;  // x = 1 and x = x_last: stark_trace_points_kernel
-  const fp* pe = a.p_evals + b * W * N;
-  fp P[W];
-#pragma unroll
-  for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + i);
-  const fp x = pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i);
-  const fp wz = fp_load(a.inv_z2 + i);  // 1 / ((x - 1)(x - r))
-  fp f = fp_zero();
-  if (j) f = fp_mul(fp_sub(x, a.x_last), fp_load(a.inv_omega + j));  // (x - r) / (x^s - 1)
-#pragma unroll 1
-  for (int c = 0; c < W; ++c) {
-    const uint64_t col = (b * W + c) * N;
-    const fp pc = fp_load(pe + (uint64_t)c * N + i);
-    const fp interp = fp_add(fp_load(a.iab + 2 * (b * W + c)), fp_mul(fp_load(a.iab + 2 * (b * W + c) + 1), x));
-    fp_store(a.b_work + col + i, fp_mul(fp_sub(pc, interp), wz));
-    if (j) {  // the 1-in-ext lanes on trace points leave D to stark_trace_points_kernel
-      const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], P);
-      const fp nxt = fp_load(pe + (uint64_t)c * N + inext);
-      fp_store(a.d_work + col + i, fp_mul(fp_sub(nxt, acc), f));
-    }
-  }
+  fp_store(out + n + i, fp_canon(x));
+  const uint32_t j = (uint32_t)i & (ext - 1);
+  fp_store(out + 2 * n + i, j ? fp_mul(fp_sub(x, x_last), fp_load(inv_omega + j)) : fp_zero());
 }
 
 // ---- the trace points x_k = g1^k (domain index k * ext): D everywhere, B at x = 1 and x = x_last, and the check ----
@@ -146,7 +121,7 @@ __global__ void __launch_bounds__(TPB) stark_trace_points_kernel(StarkArgs a) {
   fp P[W];
 #pragma unroll
   for (int v = 0; v < W; ++v) P[v] = fp_load(we + (uint64_t)v * s + k);
-  const fp x = pow_lookup(a.tw_lo, a.tw_hi, a.tw_lb, i);
+  const fp x = fp_load(a.xpow + i);
   const bool last = knext == 0;
   const fp scale = fp_mul(last ? a.x_last : fp_sub(x, a.x_last), a.inv_steps);
 #pragma unroll 1
@@ -176,7 +151,7 @@ __global__ void __launch_bounds__(TPB) stark_trace_points_kernel(StarkArgs a) {
     fp_store(a.d_work + col + i, fp_mul(num, scale));
     if (k == 0 || last) {
       // B(1) = (P'(1) - b) / (1 - r);  B(r) = (P'(r) - b) / (r - 1),  P'(x) = Q(x) / x,  1 / r = g1
-      const fp slope = fp_load(a.iab + 2 * (b * W + c) + 1);
+      const fp slope = fp_load(a.iab + 3 * (b * W + c) + 1);
       const fp qc = fp_load(qe + (uint64_t)c * s + k);
       const fp dp = last ? fp_mul(qc, a.g1) : qc;
       const fp v = fp_mul(fp_sub(dp, slope), a.inv_1_m_last);
@@ -194,37 +169,91 @@ __device__ __forceinline__ void leaf_elem(const StarkArgs& a, uint64_t b, uint32
   const uint32_t c = e < W ? e : e < 2 * W ? e - W : e - 2 * W;
   fp_to_wire_words(fp_canon(fp_load(base + (b * W + c) * a.n + x)), w);
 }
-// One thread per permute4 row: hashes the two leaf pairs (k = 3W BLAKE2s blocks each) and their parent.
-// nodes: [batch][2n] x 32 B (only [0, n) is written: the leaves stay in the evaluation arrays).
 // WIDE: the launch fills the chip several times over and the hashes use the asm rounds (blake2s.cuh); a narrow launch (one small proof),
-// where a wave per SIMD walks its 6 W + 1 compressions alone, keeps the C++ rounds (2.3 against ~4.5 us per compression there).
+// where a wave per SIMD walks its compressions alone, keeps the C++ rounds (2.3 against ~4.5 us per compression there).
 constexpr uint64_t STARK_WIDE_THREADS = 1ull << 19;
-template <bool WIDE>
-__global__ void __launch_bounds__(TPB) stark_leaves_kernel(StarkArgs a, uint32_t* nodes) {
-  const uint64_t n = a.n, q = n >> 2;
+
+// ---- D, B off the trace points (B everywhere but x = 1, x = x_last) and the packed leaves, in ONE pass -------------------------------
+// One thread per permute4 row: it computes the quotients of its four points, stores them (the linear combination reads them later) and
+// hashes the two leaf pairs (k = 3 W BLAKE2s blocks each) and their parent on the spot.  (Rounds 2-4 did this in two launches -- a
+// quotient kernel moving ~224 B per point, HBM-bound, then a leaf kernel re-reading P, D, B only to hash them, BLAKE2s-issue-bound,
+// strictly in sequence; fused, the quotient traffic runs under the other waves' hash instructions: 10.4 -> 9.3 ms per 128 proofs of
+// 2^16 steps, config 5 + 5 %, profiles/r05_c5_fused_quotients_leaves_ab.txt.)
+// nodes: [batch][2n] x 32 B (only [0, n) is written: the leaves stay in the evaluation arrays).
+// Runs AFTER stark_trace_points_kernel: D on the trace points (and B at x = 1, x = x_last) are its outputs and are loaded here.
+// Element e of the message leafA || leafB (k = 3 W elements per leaf): leaf = e < k ? la : lb, kind = (e mod k) / W (P, D, B),
+// column c = (e mod k) mod W; one BLAKE2s block = two elements.
+template <int W>
+struct QuotientPoint {  // what the quotients of one domain point keep in registers: the point's P values (the step polynomials read all of
+  fp P[W];              // them); everything else -- x, 1 / Z2(x), 1 / Z(x) -- is one table load where it is used
+  uint64_t i, inext;
+  bool on_trace, special;
+  __device__ __forceinline__ void load(const StarkArgs& a, const fp* pe, uint64_t pt) {
+    const uint64_t N = a.n;
+    i = pt;
+    on_trace = ((uint32_t)pt & (a.ext - 1)) == 0;
+    inext = (pt + a.ext) & (N - 1);
+    special = on_trace && (pt == 0 || inext == 0);  // x = 1 and x = x_last
+#pragma unroll
+    for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + pt);
+  }
+};
+template <int W, bool WIDE>
+__global__ void __launch_bounds__(TPB, (W <= 3 ? 4 : 1)) stark_quotients_leaves_kernel(StarkArgs a, uint32_t* nodes) {
+  const uint64_t N = a.n, q = N >> 2;
   const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   const uint64_t b = blockIdx.y;
   if (i >= q) return;
-  const uint32_t k = 3 * a.width;
-  uint32_t* tree = nodes + b * 2 * n * 8;
+  constexpr uint32_t k = 3 * W;
+  const fp* pe = a.p_evals + b * W * N;
+  uint32_t* tree = nodes + b * 2 * N * 8;
   b2digest d[2];
 #pragma unroll 1
   for (int s = 0; s < 2; ++s) {
     b2_init(d[s].h);
     const uint64_t la = i + (uint64_t)(2 * s) * q, lb = i + (uint64_t)(2 * s + 1) * q;
+    QuotientPoint<W> pt;
+    pt.load(a, pe, la);
+#pragma unroll 1
     for (uint32_t blk = 0; blk < k; ++blk) {
       uint32_t m[16];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const uint32_t e = 2 * blk + half;  // element index inside leafA || leafB
-        leaf_elem(a, b, e < k ? e : e - k, e < k ? la : lb, m + 8 * half);
+        const uint32_t e = 2 * blk + half;
+        if (e == k) pt.load(a, pe, lb);  // the message passes from leaf A to leaf B (uniform over the workgroup)
+        const uint32_t ee = e < k ? e : e - k, kind = ee / W, c = ee - kind * W;
+        const uint64_t col = (b * W + c) * N;
+        fp val;
+        if (kind == 0) {
+          val = fp_load(pe + (uint64_t)c * N + pt.i);  // (P[c] with a dynamic c: an L1 hit instead of a register-array index)
+        } else if (kind == 1) {
+          if (!pt.on_trace) {  // off the trace points: D = (P_c(g1 x) - step_c(P(x))) (x - r) / (x^s - 1)
+            const fp nxt = fp_load(pe + (uint64_t)c * N + pt.inext), fz = fp_load(a.fz + pt.i);  // requested before the products
+            const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], pt.P);
+            val = fp_mul(fp_sub(nxt, acc), fz);
+            fp_store(a.d_work + col + pt.i, val);
+          } else {
+            val = fp_load(a.d_work + col + pt.i);  // stark_trace_points_kernel's
+          }
+        } else {
+          if (!pt.special) {
+            const fp pc = fp_load(pe + (uint64_t)c * N + pt.i), x = fp_load(a.xpow + pt.i), wz = fp_load(a.inv_z2 + pt.i);
+            const fp* ab = a.iab + 3 * (b * W + c);  // a, (b, b 2^128)
+            const fp interp = fp_add(fp_load(ab), fp_mul2(x, fp2_load(reinterpret_cast<const fp2*>(ab + 1))));
+            val = fp_mul(fp_sub(pc, interp), wz);
+            fp_store(a.b_work + col + pt.i, val);
+          } else {
+            val = fp_load(a.b_work + col + pt.i);
+          }
+        }
+        fp_to_wire_words(fp_canon(val), m + 8 * half);
       }
       b2_compress<WIDE>(d[s].h, m, 64 * (blk + 1), blk + 1 == k);
     }
-    store8(tree + (n / 2 + 2 * i + s) * 8, d[s].h);
+    store8(tree + (N / 2 + 2 * i + s) * 8, d[s].h);
   }
   b2digest top = b2_hash_pair<WIDE>(d[0].h, d[1].h);
-  store8(tree + (n / 4 + i) * 8, top.h);
+  store8(tree + (N / 4 + i) * 8, top.h);
   if (i == 0) {
     uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     store8(tree, z);
@@ -403,19 +432,27 @@ hipError_t shk_stark_interp(const fp* trace, const fp* inputs, uint64_t steps, u
   return hipGetLastError();
 }
 
-hipError_t shk_stark_quotients(const StarkArgs& a, hipStream_t st) {
-  const dim3 grid(grid_for(a.n * a.batch)), tgrid(grid_for(a.steps * a.batch)), block(TPB);
+// D, B (all points) and mtree = merkelize_polynomial_evaluations(width, P + D + B evaluations) (stark.py:38-104, 253-257)
+hipError_t shk_stark_quotients_and_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st) {
+  if (a.n < 4) return hipErrorInvalidValue;
+  const dim3 tgrid(grid_for(a.steps * a.batch)), grid(grid_for(a.n >> 2), a.batch), block(TPB);
+  const bool wide = (a.n >> 2) * a.batch >= STARK_WIDE_THREADS;
   switch (a.width) {
-#define SHK_CASE(W)                                                           \
-  case W:                                                                     \
-    hipLaunchKernelGGL(stark_quotients_kernel<W>, grid, block, 0, st, a);     \
-    hipLaunchKernelGGL(stark_trace_points_kernel<W>, tgrid, block, 0, st, a); \
+#define SHK_CASE(W)                                                                                   \
+  case W:                                                                                             \
+    hipLaunchKernelGGL(stark_trace_points_kernel<W>, tgrid, block, 0, st, a);                         \
+    if (wide)                                                                                         \
+      hipLaunchKernelGGL((stark_quotients_leaves_kernel<W, true>), grid, block, 0, st, a, d_nodes);  \
+    else                                                                                              \
+      hipLaunchKernelGGL((stark_quotients_leaves_kernel<W, false>), grid, block, 0, st, a, d_nodes); \
     break;
     SHK_CASE(1) SHK_CASE(2) SHK_CASE(3) SHK_CASE(4) SHK_CASE(5) SHK_CASE(6) SHK_CASE(7) SHK_CASE(8) SHK_CASE(9)
 #undef SHK_CASE
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return shk_merkle_upper_levels(a.n, a.batch, d_nodes, st);
 }
 
 hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols, hipStream_t st) {
@@ -423,20 +460,10 @@ hipError_t shk_stark_qprep(const fp* pcoef, fp* q, uint64_t steps, uint64_t cols
   return hipGetLastError();
 }
 
-hipError_t shk_stark_inv_z2(fp* out, uint64_t n, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, const fp& x_last,
-                            hipStream_t st) {
-  hipLaunchKernelGGL(stark_inv_z2_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, out, n, tw_lo, tw_hi, tw_lb, x_last);
+hipError_t shk_stark_domain_tables(fp* out, uint64_t n, uint32_t ext, const fp* tw_lo, const fp* tw_hi, uint32_t tw_lb, const fp& x_last,
+                                   const fp* inv_omega, hipStream_t st) {
+  hipLaunchKernelGGL(stark_domain_tables_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, out, n, ext, tw_lo, tw_hi, tw_lb, x_last, inv_omega);
   return hipGetLastError();
-}
-
-hipError_t shk_stark_merkelize(const StarkArgs& a, uint32_t* d_nodes, hipStream_t st) {
-  if ((a.n >> 2) * a.batch >= STARK_WIDE_THREADS)
-    hipLaunchKernelGGL(stark_leaves_kernel<true>, dim3(grid_for(a.n >> 2), a.batch), dim3(TPB), 0, st, a, d_nodes);
-  else
-    hipLaunchKernelGGL(stark_leaves_kernel<false>, dim3(grid_for(a.n >> 2), a.batch), dim3(TPB), 0, st, a, d_nodes);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  return shk_merkle_upper_levels(a.n, a.batch, d_nodes, st);
 }
 
 hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint32_t width, uint32_t batch, const fp& cpow,
