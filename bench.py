@@ -116,15 +116,20 @@ class ProofShard:
         # `streams` library contexts on this GPU (each one stream and its own workspaces): successive batched launches go to them
         # in turn, so that the latency-bound tail of one launch sequence (the small FRI rounds) runs beside the wide kernels of
         # the next (include/starkhip.h: contexts are independent; device buffers belong to the device, not to a context)
+        self.host = None  # page-locked host copy of the shard's proofs (deliver())
         self.ctxs = [ctx]
         for _ in range(1, max(1, streams)):
             other = ctypes.c_void_p()
             dev.ck(L.sh_ctx_create(dev._lib.default_device(), ctypes.byref(other)), "sh_ctx_create")
             self.ctxs.append(other)
 
-    def prove_all(self):
-        """One step: every unit of the shard, `chunk` per launch sequence; asynchronous on the library stream."""
+    def prove_all(self, deliver=False):
+        """One step: every unit of the shard, `chunk` per launch sequence; asynchronous on the library stream.  deliver: every
+        launch sequence is followed by the copy of its flat proofs into page-locked host memory on the context's copy stream
+        (sh_dev_download_async): batch k's proofs cross PCIe while batch k + 1 is being proved; delivered() waits for them."""
         dev, L = self.dev, self.dev.L
+        if deliver and self.host is None and self.units:
+            self.host = dev._lib.PinnedBuffer(self.plen * len(self.units))
         for j, c in enumerate(range(0, len(self.units), self.chunk)):
             k = min(self.chunk, len(self.units) - c)
             ctx = self.ctxs[j % len(self.ctxs)]
@@ -132,6 +137,15 @@ class ProofShard:
                                         ctypes.c_void_p(self.d_inp.value + 64 * c), self.steps, self.ext, 2,
                                         self.coefs, self.exps, self.counts, 80, k,
                                         ctypes.c_void_p(self.d_proofs.value + self.plen * c)), "stark prove")
+            if deliver:
+                dev.ck(L.sh_dev_download_async(ctx, ctypes.c_void_p(self.d_proofs.value + self.plen * c),
+                                               ctypes.c_void_p(self.host.ptr.value + self.plen * c), self.plen * k), "deliver")
+
+    def delivered(self):
+        """Waits for the copies deliver=True queued; returns the host view of the shard's proofs (None for an empty shard)."""
+        for ctx in self.ctxs:
+            self.dev.ck(self.dev.L.sh_io_sync(ctx), "sh_io_sync")
+        return self.host.view if self.host is not None else None
 
     def headers(self):
         """m_root | l_root of every proof of the shard (64 B each); synchronises; raises on an invalid witness."""
@@ -162,6 +176,10 @@ class ProofShard:
         return h.hexdigest()
 
     def close(self):
+        if self.host is not None:
+            self.delivered()
+            self.host.close()
+            self.host = None
         for p in (self.d_wit, self.d_inp, self.d_proofs):
             self.dev.free(p)
         for other in self.ctxs[1:]:
@@ -289,6 +307,8 @@ def extras(dev, quick):
                                                    "fixture": "tests/golden/fri_large.json (oracle/oracle.c:fri_rec)" if gold else None}
         dev.free(dc)
         dev.free(dp)
+    # ---- the reference's Python call sites, end to end (host conversion + PCIe + GPU): what a user of the drop-in functions sees ----
+    out["callsites"] = callsite_times(quick)
     # ---- whole prover: STARK.mk_proof (stark.py:233-279) for the reference's MiMC formulation, width 2 ------------
     # step polynomials [X_1, X_1 + X_2^3] (test_stark.py:265-293); config 5's unit of work is one such proof
     from starks_amd import stark as _stark
@@ -318,6 +338,55 @@ def extras(dev, quick):
         for p_ in (dw, di, dp):
             dev.free(p_)
     return out
+
+
+def callsite_times(quick):
+    """Wall time of the reference's own call sites through starks_amd (fft.py:316-331, merkle_tree.py:36-56, fri.py:189-266), best of
+    three.  `wire` = the input is the output of an earlier stage (a wire-backed sequence, starks_amd/wireseq.py): bytes in, bytes
+    out.  `list` = the input is a Python list of 2^k ints, as a first call has it: int -> bytes conversion included (0.15-0.3 us per
+    value, i.e. most of the time)."""
+    from starks_amd import fft, fri, merkle_tree, utils
+    from starks_amd.modp import IntegersModP
+    F = IntegersModP(P)
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts) * 1e3, r
+
+    lg = 14 if quick else 20
+    n = 1 << lg
+    w = root_of(n)
+    res = {}
+    g = utils.get_power_cycle(F(w), F)  # a wire-backed sequence of n elements
+    ms, ev = best(lambda: fft.fft_1d(F, g, P, w))
+    res["fft_1d_2^%d_ms" % lg] = round(ms, 3)
+    ok = ev[n - 1] == n and ev[0] == 0  # NTT of (1, w, w^2, ...) is n at index n - 1
+    ints = g.ints()
+    ms, ev2 = best(lambda: fft.fft_1d(F, ints, P, w), 2)
+    res["fft_1d_2^%d_ms_from_a_python_list" % lg] = round(ms, 3)
+    ok = ok and ev2 == ev
+    ms, tree = best(lambda: merkle_tree.merkelize(ev))
+    res["merkelize_2^%d_ms" % lg] = round(ms, 3)
+    ms, tree2 = best(lambda: merkle_tree.merkelize(ints), 2)
+    res["merkelize_2^%d_ms_from_a_python_list" % lg] = round(ms, 3)
+    br = merkle_tree.mk_branch(tree, 12345 % n)
+    ok = ok and merkle_tree.verify_branch(tree[1], 12345 % n, br) == bytes(ev.wire()[32 * (12345 % n):32 * (12345 % n) + 32])
+    ok = ok and tree2[1] == merkle_tree.merkelize(g)[1]
+    steps = 1 << (10 if quick else 14)
+    g2 = root_of(8 * steps)
+    trace = utils.mimc_trace(3, steps)
+    poly = fft.NonBinaryFFT(F, F(pow(g2, 8, P))).inv_fft(trace)  # Poly with wire-backed coefficients
+    ms, proof = best(lambda: fri.prove_low_degree(poly, F(g2), steps, exclude_multiples_of=8))
+    res["prove_low_degree_2^%d_ms" % (steps.bit_length() - 1)] = round(ms, 3)
+    ok = ok and len(proof[-1]) == 128
+    res["checks_ok"] = bool(ok)
+    res["note"] = ("end to end per call: conversion + PCIe from pageable memory + GPU; *_from_a_python_list = a first call whose input is "
+                   "a list of Python ints; the others take the wire-backed output of an earlier stage (starks_amd/wireseq.py)")
+    return res
 
 
 CPU_WHOLE_MAX_LOG = 21  # oracle/oracle.c: a 2^21-point forward + inverse pair takes ~17 s on one core, 2^24 ~4 min
@@ -574,6 +643,28 @@ def main():
     dev = Dev()
     L, ctx = dev.L, dev.ctx
 
+    def per_rank(x):
+        """[x of rank 0, x of rank 1, ...] on every rank (all_gather_object: a few bytes, outside every timed region)."""
+        if not use_dist:
+            return [x]
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, x)
+        return out
+
+    # who runs where -- so that the first multi-GPU run explains itself: backend and world size as torch.distributed reports them,
+    # every rank's device index, PCI bus id and UUID.  With RCCL two ranks on one device are a launch error and fail the run
+    # (with gloo that is the one-GPU rehearsal of the N > 1 path and is only reported).
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name,
+          "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "uuid": str(getattr(props, "uuid", "")), "host": socket.gethostname(), "visible_devices": ndev}
+    ranks = per_rank(me)
+    ids = [(r["host"], r["uuid"] or r["pci_bus_id"]) for r in ranks]
+    rank_info = {"backend": dist.get_backend() if use_dist else None, "world_size": dist.get_world_size() if use_dist else 1,
+                 "world_size_env": world, "devices_distinct": len(set(ids)) == len(ids), "ranks": ranks}
+    if use_dist and args.backend == "nccl" and not rank_info["devices_distinct"]:
+        raise SystemExit("bench.py: two ranks share a GPU under RCCL (%r): check LOCAL_RANK / HIP_VISIBLE_DEVICES" % (ids,))
+
     def fence():
         dev.sync()
         torch.cuda.synchronize()
@@ -614,12 +705,30 @@ def main():
         ev = ctypes.c_float()
         dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev)), "timer")
         fence()
-        dt = max_over_ranks(time.perf_counter() - t0)
+        dt_own = time.perf_counter() - t0
+        dt = max_over_ranks(dt_own)
+        # the same steps with every proof DELIVERED: the flat proofs of each launch sequence are copied into page-locked host memory
+        # on the contexts' copy streams while the next sequence is being proved (STARK.mk_proof returns its proof, stark.py:233-279);
+        # a step ends when the last byte has arrived.  Reported beside the on-device figure, never as `value`.
+        for _ in range(warm_k):
+            sh.prove_all(deliver=True)
+            sh.headers()
+            sh.delivered()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(steps_k):
+            sh.prove_all(deliver=True)
+            gather_headers(sh.headers(), args.units, rank, world, dist, tdev, use_dist)
+            host_view = sh.delivered()
+        fence()
+        dt_deliv = max_over_ranks(time.perf_counter() - t1)
+        host_sha = hashlib.sha256(memoryview(host_view)).hexdigest() if host_view is not None else hashlib.sha256(b"").hexdigest()
         chk = c5_check(dev, sh, rank)
         # EVERY proof of the timed run (launches dealt to several contexts = streams running at once) against the same shard proved
         # again through ONE context: all bytes, not a sample (round 4: a race between the waves of a Merkle kernel showed only
         # when a second stream perturbed them, and only in 5-30 % of the proofs)
         chk["all_proofs_sha256"] = sh.digest_all()
+        chk["delivered_equals_device"] = host_sha == chk["all_proofs_sha256"]
         if len(sh.ctxs) > 1 and sh.units:
             dealt, sh.ctxs = sh.ctxs, sh.ctxs[:1]
             sh.prove_all()
@@ -629,13 +738,20 @@ def main():
         else:
             chk["equals_one_context_run"] = True
         ok = all_ok(chk["batch_equals_single"] and chk["verifies"] is not False and chk["equals_one_context_run"] and
-                    len(set(heads)) == len(heads))
+                    chk["delivered_equals_device"] and len(set(heads)) == len(heads))
         n = steps * 8
         res = {"units": args.units, "trace_steps": steps, "domain": n, "proofs_per_launch": chunk,
                "proofs_per_s": args.units * steps_k / dt, "ms_per_step": dt / steps_k * 1e3, "ms_per_proof": dt / steps_k / args.units * 1e3,
                "n_gpus": world, "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)],
                "proof_bytes": sh.plen, "headers_sha256": hashlib.sha256(b"".join(heads)).hexdigest(),
                "rank0_event_ms_per_step": ev.value / steps_k,
+               "proofs_per_s_delivered": args.units * steps_k / dt_deliv,
+               "delivered": {"ms_per_step": dt_deliv / steps_k * 1e3, "bytes_per_step_this_rank": sh.plen * len(mine),
+                             "over_on_device": dt_deliv / dt,
+                             "what": "every flat proof of the step in page-locked host memory at the end of the step (copies on the contexts' "
+                                     "copy streams, under the proving of the next launch sequence); witness generation is outside both "
+                                     "timed regions (sh_dev_fill_mimc_units: one sequential x <- x^3 + k chain of 2^16 steps per unit)"},
+               "per_rank_ms_per_step": per_rank(dt_own / steps_k * 1e3),
                "check": {"ok": ok, "rank0": chk}}
         sh.close()
         return res
@@ -660,7 +776,8 @@ def main():
                                    "proofs per batched launch; a step proves the whole batch once" %
                                    (args.units, args.logsteps, world, res["proofs_per_launch"]),
                        "units": args.units, "trace_steps": steps, "parallelism": "proof sharding x%d" % world},
-            "c5": res, "c5_proofs_per_s": res["proofs_per_s"],
+            "c5": res, "c5_proofs_per_s": res["proofs_per_s"], "c5_proofs_per_s_delivered": res["proofs_per_s_delivered"],
+            "ranks": rank_info,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "whole proof (NTT passes ~30 %, packed-leaf hashing ~18 %, quotients ~20 %: DESIGN.md section 5)",
@@ -698,7 +815,9 @@ def main():
     ev_ms = ctypes.c_float()
     dev.ck(L.sh_timer_stop(ctx, ctypes.byref(ev_ms)), "timer")  # HIP events on the library's stream
     fence()
-    dt_max = max_over_ranks(time.perf_counter() - t0)
+    dt_own = time.perf_counter() - t0
+    dt_max = max_over_ranks(dt_own)
+    ms_by_rank = per_rank(dt_own / args.steps * 1e3)
 
     # correctness of what was timed: x == invNTT(NTT(x)) on every element, and the forward digest of vector 0 against the
     # committed fixture (rank 0): reference-generated up to 2^20 (tests/golden/ntt.json), the pinned C oracle's above
@@ -759,6 +878,7 @@ def main():
             "n": n, "vectors_per_step": B, "elements_per_step": elems_per_step,
             "parallelism": "independent vectors x%d" % world},
         "field_mul_eq_per_s": (n // 2) * args.logn * 2 * B * args.steps * world / dt_max,
+        "ranks": rank_info, "per_rank_ms_per_step": ms_by_rank, "per_rank_elements_per_step": [elems_per_step] * world,
         "check": {"roundtrip_ok": ok, "fwd_sha256": fwd_digest, "matches_fixture": golden_ok, "fixture": golden_src},
         # `roofline` is the metric's own quantity -- algorithmic HBM bytes against the 8 TB/s peak (bound / achieved / peak / unit / frac
         # all speak of HBM); what binds this kernel is the integer-VALU issue rate: `binding_resource` and roofline_alu below
@@ -853,6 +973,7 @@ def main():
         res = run_c5(3, 1)
         line["c5"] = res
         line["c5_proofs_per_s"] = res["proofs_per_s"]
+        line["c5_proofs_per_s_delivered"] = res["proofs_per_s_delivered"]
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             cb = cpu_baseline(args.logn, B)
@@ -869,6 +990,9 @@ def main():
             if k20 in line["extra"]:
                 line["fri_commit_ms_2^20_trace"] = line["extra"][k20]["ms"]
             line["fri_commit_ms_2^14_trace"] = line["extra"]["fri_commit_steps_2^14"]["ms"]
+            for k_, v_ in line["extra"]["callsites"].items():
+                if k_.endswith("_ms") :
+                    line["callsite_" + k_] = v_
     if rank == 0:
         emit(line)
     if use_dist:

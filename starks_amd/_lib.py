@@ -74,6 +74,8 @@ def lib():
         "sh_dev_download": (i32, [c_p, c_p, c_p, u64]),
         "sh_dev_upload": (i32, [c_p, u8p, c_p, u64]),
         "sh_dev_copy": (i32, [c_p, c_p, c_p, u64]),
+        "sh_dev_download_async": (i32, [c_p, c_p, c_p, u64]),
+        "sh_io_sync": (i32, [c_p]),
         "sh_host_alloc": (i32, [c_p, u64, pp]),
         "sh_host_free": (i32, [c_p, c_p]),
         "sh_ntt_passes": (u32, [u64, u32]),
@@ -204,6 +206,9 @@ def to_wire(values, modulus=MIMC_P):
 
     One C-level `int.to_bytes` per value and one join (0.3 us per value; the per-value slice assignment this replaces
     took twice that); plain ints in range -- the common case -- take the first branch without any per-value test."""
+    wb = getattr(values, "wire_bytes", None)
+    if wb is not None:  # a WireList (wireseq.py): the bytes the device wrote, as they are
+        return wb()
     if not isinstance(values, (list, tuple)):
         values = list(values)  # an iterator must not be half consumed by the fast path before the general one starts over
     try:

@@ -96,6 +96,7 @@ struct sh_ctx {
   hipStream_t stream = nullptr;
   hipStream_t io_in = nullptr, io_out = nullptr;  // copy streams of the pipelined host-buffer transforms (created on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t io_ev = nullptr;  // orders sh_dev_download_async's copies behind the ctx stream
   std::string err;
   std::map<std::string, NttPlan*> plans;
   // plan cache accounting: least-recently-used plans are evicted on entry of a public call once the tables held exceed
@@ -1014,6 +1015,9 @@ void sh_ctx_destroy(sh_ctx* c) {
   }
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
+  if (c->io_in) (void)hipStreamSynchronize(c->io_in);
+  if (c->io_out) (void)hipStreamSynchronize(c->io_out);
+  if (c->io_ev) (void)hipEventDestroy(c->io_ev);
   if (c->io_in) (void)hipStreamDestroy(c->io_in);
   if (c->io_out) (void)hipStreamDestroy(c->io_out);
   (void)hipStreamDestroy(c->stream);
@@ -1086,6 +1090,25 @@ int sh_host_free(sh_ctx* c, void* hptr) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipHostFree(hptr));
+  return SH_OK;
+}
+int sh_dev_download_async(sh_ctx* c, const void* d_src, void* host_dst, uint64_t bytes) {
+  if (!c || (bytes && (!d_src || !host_dst))) return SH_ERR_INVALID;
+  if (!bytes) return SH_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!host_is_pinned(host_dst)) return SH_ERR_INVALID;  // a pageable destination would make the copy synchronous and staged
+  if (!c->io_out) HIP_TRY(c, hipStreamCreateWithFlags(&c->io_out, hipStreamNonBlocking));
+  if (!c->io_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->io_ev, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->io_ev, c->stream));           // behind the work queued so far ...
+  HIP_TRY(c, hipStreamWaitEvent(c->io_out, c->io_ev, 0));    // ... (the wait is enqueued, the event may be re-recorded at once)
+  HIP_TRY(c, hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->io_out));
+  return SH_OK;
+}
+int sh_io_sync(sh_ctx* c) {
+  if (!c) return SH_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->io_in) HIP_TRY(c, hipStreamSynchronize(c->io_in));
+  if (c->io_out) HIP_TRY(c, hipStreamSynchronize(c->io_out));
   return SH_OK;
 }
 int sh_dev_copy(sh_ctx* c, const void* d_src, void* d_dst, uint64_t bytes) {

@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import MIMC_P
 from .modp import IntegersModP
 from .polynomial import polynomials_over
+from .wireseq import WireList
 
 
 def _check_field(modulus):
@@ -54,10 +55,10 @@ def ntt_bytes(data, n, root_of_unity, inverse=False, batch=1, out=None):
     return out if out is not None else dst.raw
 
 
-def _elements(field, ints):
-    """device output (canonical residues) -> elements of the caller's field type"""
-    wrap = getattr(field, "wrap_canonical", None)
-    return wrap(ints) if wrap is not None else [field(x) for x in ints]
+def _elements(field, raw):
+    """device output (wire form, canonical residues) -> a lazy sequence of elements of the caller's field type (wireseq.py):
+    nothing is converted until somebody indexes or iterates, and the next stage takes the bytes as they are"""
+    return WireList(raw, field)
 
 
 def _on_device(modulus, root_of_unity):
@@ -101,9 +102,10 @@ def fft_1d(field, vals, modulus, root_of_unity, inv=False):
     if not _on_device(modulus, root_of_unity):
         return _host_dft(field, list(vals), modulus, root_of_unity, inv)
     n = _order(root_of_unity)
-    vals = list(vals)
+    if not isinstance(vals, (list, tuple, WireList)):
+        vals = list(vals)
     out = ntt_bytes(_lib.to_wire(vals), n, int(root_of_unity), inverse=inv)
-    return _elements(field, _lib.from_wire(out))
+    return _elements(field, out)
 
 
 class FFT(object):
@@ -130,10 +132,15 @@ class NonBinaryFFT(FFT):
 def mul_polys(a, b, root_of_unity):
     """starks/fft.py:334-345: returns n * (a*b) -- the reference omits the 1/n of the inverse transform."""
     field = None
-    for v in list(a) + list(b) + [root_of_unity]:
-        if hasattr(v, "p"):
-            field = type(v)
+    for seq in (a, b):
+        if isinstance(seq, WireList):
+            field = seq.field
             break
+    if field is None:
+        for v in list(a) + list(b) + [root_of_unity]:
+            if hasattr(v, "p"):
+                field = type(v)
+                break
     if field is None:
         field = IntegersModP(MIMC_P)
     if not _on_device(field.p, root_of_unity):
@@ -143,21 +150,21 @@ def mul_polys(a, b, root_of_unity):
         unscale = field(len(fa))  # _host_dft's inverse divides by n, mul_polys (fft.py:345) does not
         return [x * unscale for x in _host_dft(field, [u * v for u, v in zip(fa, fb)], field.p, root_of_unity, inv=True)]
     n = _order(root_of_unity)
-    a, b = list(a), list(b)
+    a, b = (a if isinstance(a, WireList) else list(a)), (b if isinstance(b, WireList) else list(b))
     if len(a) > n or len(b) > n:
         raise ValueError("operand longer than the order of the root of unity")
     out = ctypes.create_string_buffer(32 * n)
     rc = _lib.lib().sh_mul_polys(_lib.ctx(), _lib.to_wire(a), len(a), _lib.to_wire(b), len(b), out, n,
                                  int(root_of_unity).to_bytes(32, "big"))
     _lib.check(rc, "sh_mul_polys")
-    return _elements(field, _lib.from_wire(out.raw))
+    return _elements(field, out.raw)
 
 
 def low_degree_extension(field, trace_columns, extension_factor, G2):
     """The LDE step of STARK.mk_proof (stark.py:27-36 + 253-256): per column, inverse NTT over
     G1 = G2^extension_factor, then NTT over G2.  trace_columns: list of equal-length lists."""
     _check_field(field.p)
-    cols = [list(c) for c in trace_columns]
+    cols = [c if isinstance(c, WireList) else list(c) for c in trace_columns]
     steps = len(cols[0])
     if any(len(c) != steps for c in cols):
         raise ValueError("trace columns must have equal length")
@@ -168,5 +175,5 @@ def low_degree_extension(field, trace_columns, extension_factor, G2):
     data = b"".join(_lib.to_wire(c) for c in cols)
     rc = _lib.lib().sh_lde(_lib.ctx(), data, out, steps, extension_factor, len(cols), int(G2).to_bytes(32, "big"))
     _lib.check(rc, "sh_lde")
-    flat = _lib.from_wire(out.raw)
-    return [_elements(field, flat[c * n:(c + 1) * n]) for c in range(len(cols))]
+    raw = out.raw
+    return [_elements(field, memoryview(raw)[32 * n * c:32 * n * (c + 1)]) for c in range(len(cols))]

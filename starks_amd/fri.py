@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import MIMC_P
 from .merkle_tree import verify_branch, blake
 from .utils import get_pseudorandom_indices
+from .wireseq import WireList
 
 
 def proof_len(n, maxdeg_plus_1, samples=40):
@@ -59,11 +60,16 @@ def prove_flat(coeff_bytes, n, root_of_unity, maxdeg_plus_1, exclude_multiples_o
 
 def prove_low_degree(f, root_of_unity, maxdeg_plus_1, exclude_multiples_of=0, fri_spot_check_security_factor=40):
     """fri.py:189-266.  `f`: a Poly (its .coefficients) or a list of coefficients."""
-    coeffs = list(f.coefficients) if hasattr(f, "coefficients") else list(f)
-    for c in coeffs:
-        if hasattr(c, "p") and int(c.p) != MIMC_P:
+    coeffs = f.coefficients if hasattr(f, "coefficients") else f
+    if isinstance(coeffs, WireList):  # e.g. an inverse transform's output: the bytes go to the prover as they are
+        if int(coeffs.field.p) != MIMC_P:
             raise NotImplementedError("starks_amd accelerates the MiMC prime field only")
-        break
+    else:
+        coeffs = list(coeffs)
+        for c in coeffs:
+            if hasattr(c, "p") and int(c.p) != MIMC_P:
+                raise NotImplementedError("starks_amd accelerates the MiMC prime field only")
+            break
     n = _lib.order_of_root(root_of_unity)
     if n is None:
         raise NotImplementedError("root_of_unity must have power-of-two order")

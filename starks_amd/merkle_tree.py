@@ -4,6 +4,7 @@ import ctypes
 from hashlib import blake2s
 
 from . import _lib
+from .wireseq import NodeList, WireList
 
 
 def blake(x):
@@ -62,14 +63,14 @@ def merkelize_bytes(leaves):
 def merkelize(L):
     """merkle_tree.py:36-56.  Leaves may be ints, byte strings or field elements (:47-53).  Power-of-two counts (>= 4) of
     32-byte leaves -- every tree of the proving path -- are hashed on the GPU; anything else on the host."""
+    if isinstance(L, WireList) and len(L) >= 4 and not len(L) & (len(L) - 1):
+        return NodeList(merkelize_bytes(L.wire_bytes()))  # a transform's output goes to the tree as the bytes it is
     leaves = _leaf_list(list(L))
     n = len(leaves)
     if n < 4 or n & (n - 1) or any(len(x) != 32 for x in leaves):
         return _host_merkelize(leaves)
-    raw = merkelize_bytes(b"".join(leaves))
-    nodes = [raw[i:i + 32] for i in range(0, len(raw), 32)]
-    nodes[0] = b""  # the reference leaves b'' in slot 0
-    return nodes
+    # 2n nodes over one buffer, entry 0 reads as b"" like the reference's slot 0 (wireseq.NodeList: no 2n bytes objects)
+    return NodeList(merkelize_bytes(b"".join(leaves)))
 
 
 def mk_branch(tree, index):
@@ -104,15 +105,11 @@ def merkelize_polynomial_evaluations(dims, polynomial_evals):
         raise ValueError("all polynomials must be evaluated on the same domain")
     if n < 4 or n & (n - 1):
         raise NotImplementedError("starks_amd.merkelize needs a power-of-two number of leaves >= 4 (got %d)" % n)
-    data = b"".join(_leaf_bytes(list(e)) for e in polynomial_evals)
+    data = b"".join(e.wire_bytes() if isinstance(e, WireList) else _leaf_bytes(list(e)) for e in polynomial_evals)
     nodes = ctypes.create_string_buffer(32 * n)
     leaves = ctypes.create_string_buffer(32 * k * n)
     _lib.check(_lib.lib().sh_merkelize_packed(_lib.ctx(), data, n, k, nodes, leaves), "sh_merkelize_packed")
-    out = [nodes.raw[i:i + 32] for i in range(0, 32 * n, 32)]
-    out[0] = b""
-    w = 32 * k
-    out.extend(leaves.raw[i:i + w] for i in range(0, w * n, w))
-    return out
+    return NodeList(nodes.raw, tail=leaves.raw, tail_width=32 * k)  # n hash nodes (entry 0 = b""), then the n packed leaves
 
 
 def unpack_merkle_leaf(leaf, dims, num_polys):

@@ -1,6 +1,8 @@
 """Minimal dense univariate polynomial, enough for the hot path's boundary: `NonBinaryFFT.fft` takes one
 (its `.coefficients`, trailing zeros stripped) and `.inv_fft` returns one (starks/fft.py:263-272,
 starks/polynomial.py:13-21,58,158-164).  Schoolbook multiplication / division are out of scope."""
+from .wireseq import WireList
+
 _POLYS = {}
 
 
@@ -14,6 +16,11 @@ def polynomials_over(ring):
 
     class Polynomial(Poly):
         def __init__(self, c):
+            if isinstance(c, WireList) and c.field is ring:
+                # a transform's output (wireseq.py): trailing zeros are stripped on the bytes, no element is created
+                k = (len(c.wire_bytes().rstrip(b"\0")) + 31) // 32
+                self.coefficients = c[:k]
+                return
             if isinstance(c, Polynomial):
                 coeffs = list(c.coefficients)
             elif isinstance(c, bytes):

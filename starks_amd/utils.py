@@ -5,6 +5,7 @@ import ctypes
 from . import _lib
 from ._lib import MIMC_P
 from .merkle_tree import blake
+from .wireseq import WireList
 
 
 def get_power_cycle(r, field):
@@ -16,7 +17,7 @@ def get_power_cycle(r, field):
         raise NotImplementedError("r must have power-of-two order")
     out = ctypes.create_string_buffer(32 * n)
     _lib.check(_lib.lib().sh_power_cycle(_lib.ctx(), int(r).to_bytes(32, "big"), n, out), "sh_power_cycle")
-    return [field(x) for x in _lib.from_wire(out.raw)]
+    return WireList(out.raw, field)  # lazy: elements are created on index / iteration (wireseq.py)
 
 
 def get_pseudorandom_indices(entropy, modulus, count, exclude_multiples_of=0):

@@ -149,6 +149,51 @@ def test_reference_call_sites_fft(sa):
     assert [int(v) for v in sa.fft.mul_polys([F31(1), F31(2)], [F31(3)], F31(26))] == [(6 * 3) % 31, (6 * 6) % 31, 0, 0, 0, 0]
 
 
+def test_chained_call_sites_move_bytes_not_objects(sa, oracle):
+    """The reference's chain fft -> merkelize -> mk_branch (stark.py:253-263) and inv_fft -> prove_low_degree through the drop-in
+    functions: every stage hands the next one a wire-backed sequence (starks_amd/wireseq.py), results equal the oracle's and the
+    plain-list route's, and the whole 2^20-point chain stays far below the cost of creating 2^20 Python objects per stage."""
+    import time
+    from starks_amd.wireseq import WireList, NodeList
+    from starks_amd.polynomial import polynomials_over
+    F = sa.F
+    n = 1 << 12
+    w = root_of(n)
+    coeffs = [seeded(31, i) for i in range(n // 8)]
+    solver = sa.fft.NonBinaryFFT(F, F(w))
+    ev = solver.fft(polynomials_over(F).factory(coeffs))
+    assert isinstance(ev, WireList) and len(ev) == n and isinstance(ev[5], F)
+    want = oracle.c.fft(coeffs, n, w)
+    assert ev == want and [int(v) for v in ev[:4]] == want[:4] and ev[-1] == want[-1]
+    tree = sa.mt.merkelize(ev)
+    assert isinstance(tree, NodeList) and len(tree) == 2 * n and tree[0] == b""
+    assert tree == oracle.c.merkelize(want) and tree == sa.mt.merkelize(list(ev)) and tree == sa.mt.merkelize(want)
+    br = sa.mt.mk_branch(tree, 77)
+    assert br == oracle.c.mk_branch_bytes(oracle.c.merkelize_bytes(wire(want)), 77)
+    assert sa.mt.verify_branch(tree[1], 77, br, output_as_int=True) == want[77]
+    back = solver.inv_fft(ev)  # Poly whose coefficients are still bytes; the padding zeros are stripped on the bytes
+    assert isinstance(back.coefficients, WireList) and back.coefficients == coeffs and len(back) == n // 8
+    proof = sa.fri.prove_low_degree(back, F(w), n // 8, exclude_multiples_of=8)
+    assert proof == sa.fri.prove_low_degree(coeffs, F(w), n // 8, exclude_multiples_of=8)
+    assert sa.utils.get_power_cycle(F(w), F)[:3] == [1, w, w * w % P] and len(sa.utils.get_power_cycle(F(w), F)) == n
+    assert sa.fft.mul_polys(ev[:4], [1, 2], F(root_of(8))) == sa.fft.mul_polys(list(ev[:4]), [1, 2], F(root_of(8)))
+    packed = sa.mt.merkelize_polynomial_evaluations(1, [ev, ev[::-1]])
+    assert packed == sa.mt.merkelize_polynomial_evaluations(1, [want, want[::-1]]) and len(packed[n]) == 64
+    # at size: 2^20 points, input already wire-backed (the output of an earlier stage)
+    n = 1 << 20
+    g = sa.utils.get_power_cycle(F(root_of(n)), F)
+    t0 = time.perf_counter()
+    ev = sa.fft.fft_1d(F, g, P, root_of(n))
+    t1 = time.perf_counter()
+    tree = sa.mt.merkelize(ev)
+    t2 = time.perf_counter()
+    br = sa.mt.mk_branch(tree, 12345)
+    assert len(br) == 21 and sa.mt.verify_branch(tree[1], 12345, br) == bytes(ev.wire()[32 * 12345:32 * 12346])
+    # NTT of (1, w, w^2, ...) = n at index n - 1, zero elsewhere
+    assert ev[n - 1] == n and ev[0] == 0 and ev[123] == 0
+    assert t1 - t0 < 0.25 and t2 - t1 < 0.25, (t1 - t0, t2 - t1)  # (measured 20-30 ms each; 2^20 objects alone cost 0.5 s)
+
+
 def test_power_cycle(sa):
     g = load_golden("utils.json")
     F = sa.F
@@ -1108,8 +1153,19 @@ def test_bench_two_ranks_share_this_gpu(sa, args):
     assert c5["check"]["rank0"]["batch_equals_single"] is True and c5["check"]["rank0"]["verifies"] is True
     if line["metric"] == "ntt_field_elements_per_sec":
         assert line["check"]["roundtrip_ok"] is True and line["scaling"] == "weak"
+        assert len(line["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in line["per_rank_ms_per_step"])
+        assert line["per_rank_elements_per_step"] == [line["config"]["elements_per_step"]] * 2
     else:
         assert line["scaling"] == "strong" and line["unit"] == "proofs/s"
+    # the line explains who ran where: backend, world size as torch.distributed reports it, each rank's device
+    ri = line["ranks"]
+    assert ri["backend"] == "gloo" and ri["world_size"] == 2 and ri["world_size_env"] == 2
+    assert [r["rank"] for r in ri["ranks"]] == [0, 1] and [r["local_rank"] for r in ri["ranks"]] == [0, 1]
+    assert all(r["device_index"] == 0 and r["pci_bus_id"] and r["device_name"] for r in ri["ranks"])
+    assert ri["devices_distinct"] is False  # both ranks of this rehearsal sit on the box's one GPU (allowed with gloo only)
+    assert len(c5["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in c5["per_rank_ms_per_step"])
+    # every proof delivered to the host, and what arrived is what the device holds
+    assert c5["proofs_per_s_delivered"] > 0 and c5["check"]["rank0"]["delivered_equals_device"] is True
 
 
 @pytest.mark.parametrize("workload", ["ntt", "c5"])
@@ -1143,8 +1199,12 @@ def test_bench_rccl_collectives_with_one_rank(sa, workload):
     assert c5["check"]["rank0"]["batch_equals_single"] is True and c5["check"]["rank0"]["verifies"] is True
     if workload == "ntt":
         assert line["check"]["roundtrip_ok"] is True
+    ri = line["ranks"]
+    assert ri["backend"] == "nccl" and ri["world_size"] == 1 and ri["devices_distinct"] is True
+    assert ri["ranks"][0]["device_index"] == 0 and ri["ranks"][0]["pci_bus_id"] and ri["ranks"][0]["uuid"]
+    assert len(c5["per_rank_ms_per_step"]) == 1 and c5["check"]["rank0"]["delivered_equals_device"] is True
     other = run("gloo")
-    assert other["c5"]["headers_sha256"] == c5["headers_sha256"]
+    assert other["c5"]["headers_sha256"] == c5["headers_sha256"] and other["ranks"]["backend"] == "gloo"
 
 
 @pytest.mark.parametrize("env", [

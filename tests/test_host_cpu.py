@@ -448,3 +448,40 @@ def test_dpp_reads_keep_their_distance_from_the_producer(tmp_path):
                 waits += 1
             j -= 1
     assert checked >= 80 * 4  # 80 DPP reads per compression, in the top kernels (three leaf modes x two widths) and the sampling kernels
+
+
+def test_wire_backed_sequences_keep_list_semantics():
+    """starks_amd/wireseq.py: what the drop-in functions return instead of lists of 2^20 element objects.  Indexing (negative,
+    slices, strides, reversal), iteration, `in`, equality against lists of ints / elements / each other, concatenation, the
+    zero-copy hand-over to the next stage (_lib.to_wire), Polynomial's trailing-zero strip on the bytes, NodeList's b"" slot 0 and
+    the packed-leaf tail."""
+    from starks_amd.wireseq import WireList, NodeList
+    from starks_amd.modp import IntegersModP
+    from starks_amd._lib import MIMC_P as P, to_wire
+    from starks_amd.polynomial import polynomials_over
+    F = IntegersModP(P)
+    vals = [5, 0, P - 1, 7, 0, 0, 9, 0]
+    raw = b"".join(v.to_bytes(32, "big") for v in vals)
+    w = WireList(raw, F)
+    assert len(w) == 8 and w[2] == P - 1 and isinstance(w[0], F) and int(w[-2]) == 9 and w[3] + 1 == 8
+    with pytest.raises(IndexError):
+        w[8]
+    assert w == vals and w == [F(v) for v in vals] and w == tuple(vals) and not (w != vals) and w != vals[:-1] and w != [1] * 8
+    assert w[1:3] == [0, P - 1] and w[::2] == [5, P - 1, 0, 9] and w[::-1] == vals[::-1] and w[5:2] == [] and isinstance(w[::2], WireList)
+    assert list(w) == [F(v) for v in vals] and 7 in w and 8 not in w and (w + [1])[-1] == 1 and ([1] + w)[0] == 1
+    assert to_wire(w) is raw and to_wire(w[2:4]) == raw[64:128]  # the next stage takes the bytes as they are
+    assert w == WireList(bytes(raw), F) and w.ints() == vals and w.tolist() == vals
+    big = WireList(b"".join(i.to_bytes(32, "big") for i in range(10000)), F)  # iteration crosses its 4096-value blocks
+    assert [int(v) for v in big] == list(range(10000))
+    poly = polynomials_over(F).factory(w)
+    assert len(poly.coefficients) == 7 and poly.coefficients == vals[:7] and isinstance(poly.coefficients, WireList)
+    assert poly(2) == sum(v * 2**i for i, v in enumerate(vals)) % P
+    assert polynomials_over(F).factory(WireList(bytes(64), F)).is_zero()
+    loose = WireList((P + 3).to_bytes(32, "big"), F, canonical=False)  # unreduced bytes: elementwise semantics, reduced on access
+    assert loose == [3] and loose[0] == 3 and loose == WireList((3).to_bytes(32, "big"), F)
+    nodes = NodeList(bytes(32) + b"\x01" * 32 + b"\x02" * 32 + b"\x03" * 32)
+    assert len(nodes) == 4 and nodes[0] == b"" and nodes[1] == b"\x01" * 32 and nodes[-1] == b"\x03" * 32
+    assert nodes[1:3] == [b"\x01" * 32, b"\x02" * 32] and nodes == [b"", b"\x01" * 32, b"\x02" * 32, b"\x03" * 32]
+    assert nodes[len(nodes) // 2 + 1] == b"\x03" * 32  # mk_branch's arithmetic (merkle_tree.py:59-68) works on it unchanged
+    t = NodeList(bytes(64), tail=b"\x07" * 96 * 2, tail_width=96)
+    assert len(t) == 4 and t[2] == b"\x07" * 96 and t[0] == b"" and t[3] == b"\x07" * 96
