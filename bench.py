@@ -225,6 +225,10 @@ def c5_check(dev, sh, rank):
         pr = stark.unpack_proof(got, sh.steps, sh.ext, 2, sh.degree)
         try:  # the verifier asserts, like the reference's (stark.py:281-388): a rejected proof is a failed check, not a crash
             res["verifies"] = bool(S.verify_proof(pr, w, [(0, j, v) for j, v in enumerate(inp)]))
+            # and the library's own verifier (sh_stark_verify) on the flat bytes
+            res["verifies"] = res["verifies"] and bool(stark.verify_flat(got, b"".join(v.to_bytes(32, "big") for v in inp),
+                                                                         b"".join(col[-1].to_bytes(32, "big") for col in w),
+                                                                         sh.steps, sh.ext, 2, sh.polys))
         except AssertionError:
             res["verifies"] = False
     return res

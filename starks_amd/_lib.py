@@ -74,6 +74,8 @@ def lib():
         "sh_dev_download": (i32, [c_p, c_p, c_p, u64]),
         "sh_dev_upload": (i32, [c_p, u8p, c_p, u64]),
         "sh_dev_copy": (i32, [c_p, c_p, c_p, u64]),
+        "sh_fri_verify": (i32, [u8p, u64, u8p, u64, u8p, u64, u32, u32]),
+        "sh_stark_verify": (i32, [u8p, u64, u8p, u8p, u64, u32, u32, u8p, u8p, ctypes.POINTER(u32), u32]),
         "sh_dev_download_async": (i32, [c_p, c_p, c_p, u64]),
         "sh_io_sync": (i32, [c_p]),
         "sh_host_alloc": (i32, [c_p, u64, pp]),

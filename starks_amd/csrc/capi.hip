@@ -969,6 +969,7 @@ const char* sh_strerror(int status) {
     case SH_ERR_UNSUPPORTED: return "unsupported size";
     case SH_ERR_CONSTRAINT: return "the witness violates a transition constraint";
     case SH_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case SH_ERR_REJECTED: return "proof rejected";
     default: return "unknown status";
   }
 }

@@ -151,6 +151,17 @@ def verify_low_degree_proof(proof, merkle_root, root_of_unity, maxdeg_plus_1, ex
     return True
 
 
+def verify_flat(flat, merkle_root, n, root_of_unity, maxdeg_plus_1, exclude_multiples_of=0, samples=40):
+    """The library's own verifier (sh_fri_verify: host C++ behind the C ABI, same decisions as verify_low_degree_proof above) on a
+    FLAT proof as prove_flat returns it.  True / AssertionError like the reference's verifier."""
+    rc = _lib.lib().sh_fri_verify(bytes(flat), len(flat), bytes(merkle_root), n, int(root_of_unity).to_bytes(32, "big"),
+                                  maxdeg_plus_1, exclude_multiples_of, samples)
+    if rc == -9:
+        raise AssertionError("FRI proof rejected")
+    _lib.check(rc, "sh_fri_verify")
+    return True
+
+
 class SmoothSubgroupFRI(object):
     """fri.py:176-366 (class name and method signatures of the reference's commented-out driver)."""
 

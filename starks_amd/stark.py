@@ -110,6 +110,18 @@ def prove_flat(witness_bytes, input_bytes, steps, ext, width, step_polys, batch=
     return out.raw
 
 
+def verify_flat(flat, input_bytes, output_bytes, steps, ext, width, step_polys, samples=SPOT_CHECKS):
+    """The library's own verifier (sh_stark_verify: host C++ behind the C ABI; the decisions of STARK.verify_proof below) on a FLAT
+    proof as prove_flat returns it.  input_bytes / output_bytes: [width] wire-form boundary inputs and witness[dim][-1]."""
+    coefs, exps, counts, _ = pack_step_polys(step_polys, width)
+    rc = _lib.lib().sh_stark_verify(bytes(flat), len(flat), bytes(input_bytes), bytes(output_bytes), steps, ext, width, coefs, exps,
+                                    counts, samples)
+    if rc == -9:
+        raise AssertionError("STARK proof rejected")
+    _lib.check(rc, "sh_stark_verify")
+    return True
+
+
 class STARK(object):
     """Generates and verifies STARKs (stark.py:179-402); same constructor arguments."""
 

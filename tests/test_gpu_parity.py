@@ -440,6 +440,11 @@ def test_full_size_fri_prove_then_verify(sa, logsteps):
     assert L.sh_dev_download(ctx, dt, root, 64) == 0
     mroot = root.raw[32:64]
     assert sa.fri.verify_low_degree_proof(proof, mroot, g2, steps, ext)
+    assert sa.fri.verify_flat(flat.raw, mroot, n, g2, steps, ext, 40)  # sh_fri_verify: the same decision from the flat bytes
+    tampered = bytearray(flat.raw)
+    tampered[40000] ^= 1
+    with pytest.raises(AssertionError):
+        sa.fri.verify_flat(bytes(tampered), mroot, n, g2, steps, ext, 40)
     bad = [[proof[0][0], [[list(b) for b in bs] for bs in proof[0][1]]]] + proof[1:]
     bad[0][1][7][2][0] = bytes(32)
     with pytest.raises(AssertionError):
@@ -812,6 +817,15 @@ def test_stark_large_prove_then_verify(sa, oracle, logsteps):
     pr = S.mk_proof(w, boundary)
     assert S.verify_proof(pr, w, boundary)
     assert oracle.py.verify_stark_proof(pr, [c[-1] for c in w], inputs, sp, steps, ext)
+    # the library's own verifier (sh_stark_verify, host C++ behind the C ABI) on the flat bytes, and on a flipped byte
+    flat = stark.prove_flat(b"".join(wire(col) for col in w), wire(inputs), steps, ext, 2, polys)
+    assert stark.unpack_proof(flat, steps, ext, 2, 3) == pr
+    outs = wire(c[-1] for c in w)
+    assert stark.verify_flat(flat, wire(inputs), outs, steps, ext, 2, polys)
+    bad = bytearray(flat)
+    bad[len(bad) // 3] ^= 4
+    with pytest.raises(AssertionError):
+        stark.verify_flat(bytes(bad), wire(inputs), outs, steps, ext, 2, polys)
     # the P evaluations inside the leaves are the low-degree extension of the witness
     pos = sa.utils.get_pseudorandom_indices(pr[1], steps * ext, 80, exclude_multiples_of=ext)[0]
     leaf = sa.mt.unpack_merkle_leaf(pr[2][0][0], 2, 3)
