@@ -17,7 +17,7 @@ columns per launch sequence), `fri_commit_ms_2^20_trace` / `fri_commit_ms_2^14_t
 
 Workload `c5` (BASELINE configs[4]): `--units` (512) independent 2^16-step MiMC STARK proofs (STARK.mk_proof,
 stark.py:233-279; unit j = test_stark.py:265-293 started from 3 + j), sharded over the ranks by proof index
-(starks_amd/batch.py:shard), `--chunk` (128; fewer when a rank's shard would leave a context idle) proofs per batched launch, the launches dealt in turn to `--c5-streams` (2) library
+(starks_amd/batch.py:shard), `--chunk` (256; fewer when a rank's shard would leave a context idle) proofs per batched launch, the launches dealt in turn to `--c5-streams` (2) library
 contexts; a step = the whole batch once; `value` = proofs/s; strong
 scaling; the only exchange is one all_gather of the 64-byte proof headers (m_root | l_root) per step (RCCL).  Every run of
 the default workload also runs three such steps after its timed region and reports it under `c5` / `c5_proofs_per_s`, so
@@ -130,8 +130,7 @@ class ProofShard:
         dev, L = self.dev, self.dev.L
         if deliver and self.host is None and self.units:
             self.host = dev._lib.PinnedBuffer(self.plen * len(self.units))
-        for j, c in enumerate(range(0, len(self.units), self.chunk)):
-            k = min(self.chunk, len(self.units) - c)
+        for j, (c, k) in enumerate(self.schedule(deliver)):
             ctx = self.ctxs[j % len(self.ctxs)]
             dev.ck(L.sh_dev_stark_prove(ctx, ctypes.c_void_p(self.d_wit.value + self.wbytes * c),
                                         ctypes.c_void_p(self.d_inp.value + 64 * c), self.steps, self.ext, 2,
@@ -140,6 +139,20 @@ class ProofShard:
             if deliver:
                 dev.ck(L.sh_dev_download_async(ctx, ctypes.c_void_p(self.d_proofs.value + self.plen * c),
                                                ctypes.c_void_p(self.host.ptr.value + self.plen * c), self.plen * k), "deliver")
+
+    def schedule(self, deliver):
+        """[(first unit, units)] of the step's launch sequences.  On the device: `chunk` units each.  Delivering: the same, but the tail
+        halves from launch to launch (256, 128, 64, 32, 32 for 512 units) -- the copy of a launch's proofs can only start when the launch
+        has finished, so the last launch's copy is the one nothing hides, and it should be small."""
+        out, c, rem = [], 0, len(self.units)
+        while rem > 0:
+            k = min(self.chunk, rem)
+            if deliver and rem - k < k and k > 32:
+                k = max(32, (rem // 2 + 15) // 16 * 16)
+            out.append((c, k))
+            c += k
+            rem -= k
+        return out
 
     def delivered(self):
         """Waits for the copies deliver=True queued; returns the host view of the shard's proofs (None for an empty shard)."""
@@ -583,7 +596,8 @@ def main():
                     "of a trace: one launch sequence covers all of them)")
     ap.add_argument("--units", type=int, default=None, help="c5: proofs in the batch (512; 16 with --quick)")
     ap.add_argument("--logsteps", type=int, default=None, help="c5: log2 trace length (16; 10 with --quick)")
-    ap.add_argument("--chunk", type=int, default=128, help="c5: proofs per batched launch")
+    ap.add_argument("--chunk", type=int, default=256, help="c5: proofs per batched launch (measured: 256 x 2 contexts 5.27-5.29 k proofs/s "
+                    "against 128 x 2 5.19-5.24 k, 64 x 2 5.07-5.12 k)")
     ap.add_argument("--c5-streams", type=int, default=2, help="c5: library contexts (streams) the batched launches are dealt to "
                     "in turn (measured: 2 is worth 1-1.5 %% over 1; 3 and 4 no more)")
     ap.add_argument("--no-extras", action="store_true")
@@ -751,6 +765,7 @@ def main():
                "rank0_event_ms_per_step": ev.value / steps_k,
                "proofs_per_s_delivered": args.units * steps_k / dt_deliv,
                "delivered": {"ms_per_step": dt_deliv / steps_k * 1e3, "bytes_per_step_this_rank": sh.plen * len(mine),
+                             "proofs_per_launch": [k for _, k in sh.schedule(True)],
                              "over_on_device": dt_deliv / dt,
                              "what": "every flat proof of the step in page-locked host memory at the end of the step (copies on the contexts' "
                                      "copy streams, under the proving of the next launch sequence); witness generation is outside both "
@@ -856,12 +871,17 @@ def main():
     value = elems_per_step * args.steps * world / dt_max
     alg_bytes = 64.0 * elems_per_step * args.steps  # 64 B per element per transform
     achieved = alg_bytes / (ev_ms.value * 1e-3) / 1e9
-    traffic, traffic_src, lane_instr, lane_src = None, None, None, None
-    for tf in ("r04_traffic_2p%d.json" % args.logn, "r03_traffic_2p%d.json" % args.logn, "r02_traffic_2p%d.json" % args.logn):
+    traffic, traffic_src, lane_instr, lane_src, prof_us = None, None, None, None, None
+    for tf in ("r05_traffic_2p%d.json" % args.logn, "r04_traffic_2p%d.json" % args.logn, "r03_traffic_2p%d.json" % args.logn,
+               "r02_traffic_2p%d.json" % args.logn):
         try:  # HBM bytes and VALU instructions per launch from the committed PMC runs of this same command (tools/r04/prof_bench.sh)
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if tj.get("logn", 20) == args.logn and tj.get("vectors_per_step", 1) == B:
                 traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]
+                # the launch durations of the profiled session, next to this run's (drift between the two = the counters are stale)
+                ks = [k for k in tj.get("kernels", {}).values() if k.get("launches")]
+                if ks:
+                    prof_us = sum(k["avg_duration_us_kernel_trace"] * k["launches"] for k in ks) / sum(k["launches"] for k in ks)
                 traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)" % tf
                 if "lane_instructions_per_element_per_transform" in tj:
                     lane_instr = tj["lane_instructions_per_element_per_transform"]
@@ -893,6 +913,7 @@ def main():
                      "kernel": "ntt_pass_kernel (%d launches per 2^%d transform; all passes of both directions averaged)" %
                                (passes, args.logn),
                      "avg_launch_us": ev_ms.value * 1e3 / (2 * passes * args.steps),
+                     "traffic_profile_avg_launch_us": prof_us,
                      # the same launches by the bytes they really move (PMC traffic per launch / live launch duration): how far
                      # the pass is from the memory roof, as opposed to `frac`, which counts every element once per transform
                      "hbm_traffic_GBps": (traffic / (ev_ms.value * 1e-3 / (2 * passes * args.steps)) / 1e9) if traffic else None,
