@@ -874,7 +874,7 @@ def main():
     traffic, traffic_src, lane_instr, lane_src, prof_us = None, None, None, None, None
     for tf in ("r05_traffic_2p%d.json" % args.logn, "r04_traffic_2p%d.json" % args.logn, "r03_traffic_2p%d.json" % args.logn,
                "r02_traffic_2p%d.json" % args.logn):
-        try:  # HBM bytes and VALU instructions per launch from the committed PMC runs of this same command (tools/r04/prof_bench.sh)
+        try:  # HBM bytes and VALU instructions per launch from the committed PMC runs of this same command (tools/prof_bench.sh)
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if tj.get("logn", 20) == args.logn and tj.get("vectors_per_step", 1) == B:
                 traffic = tj["ntt_pass_kernel_mean_hbm_bytes_per_launch"]

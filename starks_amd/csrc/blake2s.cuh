@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t b2q_word(const uint32_t* slots, uint32_t byt
 // wait states" hazard never arises and no s_nop is needed (the compiler's own form: 20 v_mov_b32_dpp and 55 s_nop per compression).
 // In the diagonal step lane q therefore works on the diagonal of b_q, i.e. diagonal q - 1 (its message words: B2Q_DIAG_SHIFT above), and
 // afterwards holds a of column q - 1, c of column q + 1, d of column q + 2.  0.874 -> 0.62 us per compression for a wave alone on its
-// SIMD (tools/r04/quad_latency.hip), which is what a serial tree level costs.  PA / PC / PD: the lane that lane q takes a / c / d from.
+// SIMD (lab/r04/quad_latency.hip), which is what a serial tree level costs.  PA / PC / PD: the lane that lane q takes a / c / d from.
 // (The first half-round has nothing to move and its inputs may have been written by the instruction right before it: plain form.)
 // -DB2Q_NO_ASM keeps the C++ form (A/B builds).
 #if !defined(B2Q_NO_ASM)

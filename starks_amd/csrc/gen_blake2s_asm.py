@@ -3,7 +3,7 @@
 form) as gfx950 inline-asm blocks: four columns (or diagonals) in lock-step, plain two-operand adds, and a taken branch to
 the next instruction after every group of rotates.
 
-Why (profiles/r04_blake2s_issue_rate_study.txt; microbenchmarks under tools/r04).  On gfx950 v_add_u32 / v_xor_b32 (VOP2)
+Why (profiles/r04_blake2s_issue_rate_study.txt; microbenchmarks under lab/r04).  On gfx950 v_add_u32 / v_xor_b32 (VOP2)
 issue at about 0.9 ns per wave-instruction per SIMD and v_alignbit_b32 / v_add3_u32 (VOP3) at about 1.72 ns -- but in a long
 mixed straight-line stream such as this hash the fast ones cost 1.5-1.6 ns, whatever their order: runs of 24 fast instructions
 recover the fast rate in a 32-instruction LOOP body and lose it again in a 224-instruction one.  The difference is the loop's

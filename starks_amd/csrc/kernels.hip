@@ -157,7 +157,7 @@ __device__ __forceinline__ void unpack4(const uint4& v, uint32_t* w) { w[0] = v.
 // nodes above them; a workgroup handles MERKLE_ROWS consecutive tiles of 256 rows.  grid = (ceil(n/4 / (256 * MERKLE_ROWS)), batch).
 // STORE = false skips writing the leaf level (a third of the kernel's traffic): the callers that keep the value array
 // alive next to the tree (FRI rounds, the STARK l tree) re-derive a sampled leaf from its value when they gather branches.
-// Round 4 (lab: tools/r04/merkle_lab.hip): without the leaf level the pair level goes out per wave (wave_store_chunks) from 16 KiB
+// Round 4 (lab: lab/r04/merkle_lab.hip): without the leaf level the pair level goes out per wave (wave_store_chunks) from 16 KiB
 // of LDS: 409 -> 339 us for 2^24 values.  (Two tiles per workgroup, MERKLE_ROWS = 2: 363 -> 334 us in the lab with the leaf
 // level stored, nothing in the library -- 407 vs 411 us -- and slower on small trees: not taken.)
 // WIDE = the launch fills the chip several times over: the hashes use the asm rounds (blake2s.cuh); small launches, where a wave

@@ -198,7 +198,7 @@ def test_generated_asm_includes_are_current(tmp_path):
 def test_pair_constant_product_on_the_host(tmp_path):
     """fp_mul2 (csrc/fp256.cuh: the product by a table constant kept as the pair (w, w 2^128 mod p), what every NTT
     butterfly uses) against fp_mul through the portable C paths of the same header: 400 k random and edge operands, canonical
-    and lazily reduced second images.  The device's inline-asm path is pinned by the GPU parity tests and tools/mul2_bench."""
+    and lazily reduced second images.  The device's inline-asm path is pinned by the GPU parity tests and lab/r01_r03/mul2_bench.hip."""
     import subprocess
     src = os.path.join(ROOT, "tests", "native", "mul2_host.cpp")
     exe = tmp_path / "mul2_host"

@@ -2,9 +2,9 @@
 """The non-NTT kernels of the hot path at the sizes the bench reports, for rocprofv3 (kernel trace or one --pmc pass):
 merkelize of 2^24 stored leaves (merkle_leaves_kernel<false,true>, merkle_mid_kernel, merkle_top_kernel), a FRI commit of a
 2^20-step trace (merkle_leaves_kernel<false,false>, fri_fold_kernel, sample / gather) and a batch of 2^16-step STARK proofs
-(stark_leaves_kernel, stark_quotients_kernel, stark_lincomb_leaves_kernel).  Args: reps (default 3)."""
+(stark_quotients_leaves_kernel, stark_lincomb_leaves_kernel).  Args: reps (default 3)."""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import Dev, root_of, ProofShard
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 dev = Dev(); L, ctx = dev.L, dev.ctx
