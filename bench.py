@@ -141,18 +141,7 @@ class ProofShard:
                                                ctypes.c_void_p(self.host.ptr.value + self.plen * c), self.plen * k), "deliver")
 
     def schedule(self, deliver):
-        """[(first unit, units)] of the step's launch sequences.  On the device: `chunk` units each.  Delivering: the same, but the tail
-        halves from launch to launch (256, 128, 64, 32, 32 for 512 units) -- the copy of a launch's proofs can only start when the launch
-        has finished, so the last launch's copy is the one nothing hides, and it should be small."""
-        out, c, rem = [], 0, len(self.units)
-        while rem > 0:
-            k = min(self.chunk, rem)
-            if deliver and rem - k < k and k > 32:
-                k = max(32, (rem // 2 + 15) // 16 * 16)
-            out.append((c, k))
-            c += k
-            rem -= k
-        return out
+        return launch_schedule(len(self.units), self.chunk, deliver)
 
     def delivered(self):
         """Waits for the copies deliver=True queued; returns the host view of the shard's proofs (None for an empty shard)."""
@@ -198,6 +187,21 @@ class ProofShard:
         for other in self.ctxs[1:]:
             self.dev.L.sh_ctx_destroy(other)
         self.ctxs = self.ctxs[:1]
+
+
+def launch_schedule(units, chunk, deliver):
+    """[(first unit, units)] of a step's launch sequences.  On the device: `chunk` units each.  Delivering: the same, but the tail
+    halves from launch to launch (256, 128, 64, 32, 32 for 512 units) -- the copy of a launch's proofs can only start when the launch
+    has finished, so the last launch's copy is the one nothing hides, and it should be small."""
+    out, c, rem = [], 0, units
+    while rem > 0:
+        k = min(chunk, rem)
+        if deliver and rem - k < k and k > 32:
+            k = max(32, (rem // 2 + 15) // 16 * 16)
+        out.append((c, k))
+        c += k
+        rem -= k
+    return out
 
 
 def gather_headers(local, total, rank, world, dist, tdev, force=False):

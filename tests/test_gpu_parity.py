@@ -1313,6 +1313,30 @@ def test_two_contexts_in_one_process(sa, oracle):
     assert L.sh_dev_free(ctx, dx) == 0
 
 
+def test_async_download_delivers_what_the_device_holds(sa):
+    """sh_dev_download_async: device -> page-locked host memory on the context's copy stream, ordered behind the work queued on the ctx
+    stream; complete after sh_io_sync; a pageable destination is refused (it would turn the copy into a staged, synchronous one)."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << 16
+    w = root_of(n).to_bytes(32, "big")
+    dx = ctypes.c_void_p()
+    assert L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dx)) == 0
+    host = sa.lib.PinnedBuffer(32 * n)
+    want = ctypes.create_string_buffer(32 * n)
+    for seed in (1, 2, 3):  # the copy waits for the fill + transform queued before it, and does not see the next round's
+        assert L.sh_dev_fill_seeded(ctx, dx, n, seed) == 0
+        assert L.sh_dev_ntt(ctx, dx, dx, n, 1, w, 0) == 0
+        assert L.sh_dev_download_async(ctx, dx, host.ptr, 32 * n) == 0
+        assert L.sh_io_sync(ctx) == 0
+        assert L.sh_dev_download(ctx, dx, want, 32 * n) == 0
+        assert bytes(host.view) == want.raw
+    assert L.sh_dev_download_async(ctx, dx, want, 32 * n) == -1  # pageable
+    assert L.sh_dev_download_async(ctx, dx, host.ptr, 0) == 0 and L.sh_io_sync(ctx) == 0
+    host.close()
+    assert L.sh_dev_free(ctx, dx) == 0
+
+
 def test_pinned_buffer_outlives_its_context():
     """A page-locked buffer belongs to the process: sh_host_free(NULL, ptr) releases it after the allocating context is gone
     (what PinnedBuffer.close does after _lib.close()), and a double close is harmless."""

@@ -485,3 +485,18 @@ def test_wire_backed_sequences_keep_list_semantics():
     assert nodes[len(nodes) // 2 + 1] == b"\x03" * 32  # mk_branch's arithmetic (merkle_tree.py:59-68) works on it unchanged
     t = NodeList(bytes(64), tail=b"\x07" * 96 * 2, tail_width=96)
     assert len(t) == 4 and t[2] == b"\x07" * 96 and t[0] == b"" and t[3] == b"\x07" * 96
+
+
+def test_bench_launch_schedule_covers_every_unit_once():
+    """bench.py's launch sizes (on the device: equal chunks; delivering: a halving tail, so that the one copy nothing hides is small):
+    every unit exactly once, in order, for every shard size the N = 1 .. 8 runs produce."""
+    import bench
+    for units in (0, 1, 31, 32, 33, 64, 128, 171, 256, 512, 1000):
+        for chunk in (32, 64, 128, 256):
+            for deliver in (False, True):
+                sch = bench.launch_schedule(units, chunk, deliver)
+                assert [c for c, _ in sch] == [sum(k for _, k in sch[:i]) for i in range(len(sch))]
+                assert sum(k for _, k in sch) == units and all(0 < k <= chunk for _, k in sch)
+    assert [k for _, k in bench.launch_schedule(512, 256, True)] == [256, 128, 64, 32, 32]
+    assert [k for _, k in bench.launch_schedule(512, 256, False)] == [256, 256]
+    assert [k for _, k in bench.launch_schedule(64, 32, True)] == [32, 32]
