@@ -579,11 +579,19 @@ def dry_run(args, rank, world):
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     allh = gather_headers(local, args.units, rank, world, dist, "cpu")
     ok = allh == [hashlib.sha256(b"unit-%d" % j).digest() * 2 for j in range(args.units)]
+    # the rank records of a real run (who runs where), without the device properties: the same all_gather_object over the control plane
+    me = {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "host": socket.gethostname(), "units": len(mine)}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     if rank == 0:
         emit({"metric": "dry-run", "value": None, "unit": None, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "dry_run": True, "data": "none (plumbing only, no GPU work)",
                           "config": {"workload": args.workload, "units": args.units}, "gather_ok": ok,
-                          "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)]})
+                          "units_per_rank": [len(shard(args.units, r, world)) for r in range(world)],
+                          "ranks": {"backend": dist.get_backend() if world > 1 else None,
+                                    "world_size": dist.get_world_size() if world > 1 else 1, "ranks": ranks}})
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1

@@ -78,6 +78,17 @@ def test_bench_spawns_its_own_ranks():
     assert one["n_gpus"] == 1 and one["units_per_rank"] == [5]
 
 
+def test_bench_eight_ranks_dry_run():
+    """The shape of the driver's 8-GPU run, on CPU: eight ranks over gloo, config 5's 512 units sharded 64 per rank, the header
+    all_gather and the all_gather_object of the rank records (what a real run reports under `ranks`)."""
+    line = _bench(["--gpus", "8", "--workload", "c5", "--units", "512", "--dry-run"], timeout=600)
+    assert line["n_gpus"] == 8 and line["units_per_rank"] == [64] * 8 and line["gather_ok"] is True
+    ri = line["ranks"]
+    assert ri["backend"] == "gloo" and ri["world_size"] == 8
+    assert [r["rank"] for r in ri["ranks"]] == list(range(8)) and [r["local_rank"] for r in ri["ranks"]] == list(range(8))
+    assert [r["units"] for r in ri["ranks"]] == [64] * 8
+
+
 def test_bench_refuses_to_run_without_gpu():
     """No CPU fallback in the bench either: without --dry-run and without a GPU it fails loudly."""
     import __graft_entry__ as ge
