@@ -255,7 +255,7 @@ int sh_stark_verify(const uint8_t* proof, uint64_t proof_len, const uint8_t* inp
     coef[t] = f_from_wire(term_coefs + 32 * t);
     uint32_t sum = 0;
     for (uint32_t v = 0; v < width; ++v) sum += term_exps[(size_t)t * width + v];
-    if (!f_is_zero(coef[t]) && sum > degree) degree = sum;
+    if (sum > degree) degree = sum;  // as sh_stark_prove takes it (capi.hip:stark_terms): every listed term counts
   }
   Cursor cur{proof, proof_len};
   const uint8_t* m_root = cur.take(32);
