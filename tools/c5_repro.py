@@ -2,14 +2,14 @@
 """Determinism check of the many-proof workload (config 5): the 512 proofs proved through 1 and through 2 library contexts, several
 times over, compared byte for byte with the first single-context run; a difference is reported by unit, offset and proof region.
 
-    python tools/r04/c5_repro.py [--iters 8] [--streams 2] [--units 512] [--chunk 128] [--ntt-first]
+    python tools/c5_repro.py [--iters 8] [--streams 2] [--units 512] [--chunk 128] [--ntt-first]
 """
 import argparse
 import ctypes
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
