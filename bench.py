@@ -237,6 +237,15 @@ def c5_check(dev, sh, rank):
     wit = b"".join(b"".join(v.to_bytes(32, "big") for v in col) for col in w)
     single = stark.prove_flat(wit, b"".join(v.to_bytes(32, "big") for v in inp), sh.steps, sh.ext, 2, sh.polys)
     res = {"unit": sh.units[i], "batch_equals_single": got == single, "sha256": hashlib.sha256(got).hexdigest(), "verifies": None}
+    if sh.units[0] == 0:
+        # unit 0 against the proof the coefficient-form oracle wrote for this size (tests/golden/stark_large.json; None when the file
+        # has no case of this size)
+        try:
+            gold = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "stark_large.json")))["cases"]
+                    if c["steps"] == sh.steps and c["ext"] == sh.ext and c["unit"] == 0]
+        except Exception:
+            gold = []
+        res["unit0_matches_oracle_fixture"] = (hashlib.sha256(sh.proof(0)).hexdigest() == gold[0]["proof_sha256"]) if gold else None
     if rank == 0:
         S = stark.STARK(IntegersModP(P), sh.steps, sh.ext, 2, sh.polys)
         pr = stark.unpack_proof(got, sh.steps, sh.ext, 2, sh.degree)
@@ -768,7 +777,8 @@ def main():
         else:
             chk["equals_one_context_run"] = True
         ok = all_ok(chk["batch_equals_single"] and chk["verifies"] is not False and chk["equals_one_context_run"] and
-                    chk["delivered_equals_device"] and len(set(heads)) == len(heads))
+                    chk["delivered_equals_device"] and chk.get("unit0_matches_oracle_fixture") is not False and
+                    len(set(heads)) == len(heads))
         n = steps * 8
         res = {"units": args.units, "trace_steps": steps, "domain": n, "proofs_per_launch": chunk,
                "proofs_per_s": args.units * steps_k / dt, "ms_per_step": dt / steps_k * 1e3, "ms_per_proof": dt / steps_k / args.units * 1e3,

@@ -8,6 +8,7 @@ reference cannot reach (BASELINE configs[3]).
     python3 tests/golden/generate_large.py          # writes tests/golden/ntt_large.json  (about 4 min, 4 GB)
     python3 tests/golden/generate_large.py --missing  # keeps the cases already in the file, adds the sizes it lacks
     python3 tests/golden/generate_large.py --fri      # writes tests/golden/fri_large.json (about 3 min, 3 GB): below
+    python3 tests/golden/generate_large.py --stark [12 14 16]  # writes / extends tests/golden/stark_large.json: see stark_main
 
 2^17 is the domain of config 3's commit, whose default plan (9, 8) the reference-generated fixtures reach only through the
 sparse first pass (a dense vector of that length: here).  2^19 is the domain of config 5's proofs (plan (9, 10)), 2^21 the first three-pass plan, 2^23 the domain of the metric's
@@ -75,9 +76,54 @@ def fri_main():
                    "cases": cases}, fh, indent=1)
 
 
+STARK_LOGSTEPS = (12, 14, 16)
+
+
+def stark_main():
+    """--stark [LOGSTEPS ...]: whole STARK proofs of config 5's unit 0 (the reference's MiMC formulation, width 2, step polynomials
+    [X1, X1 + X2^3], inputs [42, 3], 8x extension, 80 spot checks) at sizes far beyond the reference's own reach, written by the
+    COEFFICIENT-FORM prover of oracle/pyoracle.py (the reference's construction, stark.py:27-279: schoolbook polynomial products and
+    divisions, quadratic: 40 s for 2^12 steps, 9 min for 2^14, about 2.5 h for 2^16 = config 5's own size), which test_oracle_golden.py
+    pins to the live reference on nine smaller cases.  The device prover evaluates the same polynomials on the domain instead; the GPU
+    suite compares the flat proof bytes (tests/golden/stark_large.json)."""
+    from oracle import pyoracle as po
+    out = os.path.join(HERE, "stark_large.json")
+    cases = []
+    if os.path.exists(out):
+        with open(out) as fh:
+            cases = json.load(fh)["cases"]
+    have = {c["logsteps"] for c in cases}
+    want = [int(a) for a in sys.argv[1:] if a.isdigit()] or list(STARK_LOGSTEPS)
+    sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
+    for logsteps in want:
+        if logsteps in have:
+            continue
+        steps, ext, inputs = 1 << logsteps, 8, [42, 3]
+        t0 = time.time()
+        w = po.get_computational_trace(inputs, steps, sp)
+        proof = po.mk_stark_proof(w, inputs, sp, steps, ext)
+        flat = po.stark_flat(proof)
+        case = {"logsteps": logsteps, "steps": steps, "ext": ext, "width": 2, "inputs": inputs, "unit": 0,
+                "step_polys": [[[list(k), v] for k, v in sorted(d.items())] for d in sp], "samples": 80,
+                "outputs": ["%064x" % col[-1] for col in w], "m_root": proof[0].hex(), "l_root": proof[1].hex(),
+                "proof_bytes": len(flat), "proof_sha256": hashlib.sha256(flat).hexdigest(), "oracle_seconds": round(time.time() - t0, 1)}
+        print(case, flush=True)
+        # re-read: several sizes may be generated by concurrent processes
+        if os.path.exists(out):
+            with open(out) as fh:
+                cases = json.load(fh)["cases"]
+        cases = [c for c in cases if c["logsteps"] != logsteps] + [case]
+        cases.sort(key=lambda c: c["logsteps"])
+        with open(out, "w") as fh:
+            json.dump({"generator": "tests/golden/generate_large.py --stark (oracle/pyoracle.py:mk_stark_proof, the coefficient-form prover "
+                                    "pinned to the reference by stark.json)", "cases": cases}, fh, indent=1)
+
+
 def main():
     if "--fri" in sys.argv[1:]:
         return fri_main()
+    if "--stark" in sys.argv[1:]:
+        return stark_main()
     out = os.path.join(HERE, "ntt_large.json")
     cases = []
     if "--missing" in sys.argv[1:] and os.path.exists(out):

@@ -836,6 +836,41 @@ def test_stark_large_prove_then_verify(sa, oracle, logsteps):
     # the boundary + transition identities the verifiers checked at 80 random points of a degree < steps polynomial
 
 
+def _stark_large_cases():
+    try:
+        return load_golden("stark_large.json")["cases"]
+    except Exception:
+        return []
+
+
+@pytest.mark.parametrize("c", _stark_large_cases(), ids=lambda c: "steps_2^%d" % c["logsteps"])
+def test_stark_proofs_at_size_vs_coefficient_form_oracle_fixture(sa, c):
+    """Whole STARK proofs of config 5's unit 0 at 2^12, 2^14 and 2^16 steps (config 5's own size) byte for byte against the proofs the
+    COEFFICIENT-FORM prover of oracle/pyoracle.py wrote (the reference's construction, quadratic: 9 min for 2^14 steps, hours for 2^16;
+    tests/golden/stark_large.json, generate_large.py --stark) -- through the host-buffer entry point, and through the device-resident
+    batched one that bench.py's config 5 times (unit 0 inside a batch of 4)."""
+    import ctypes
+    from starks_amd import batch, stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    steps, ext = c["steps"], c["ext"]
+    X1, X2 = generate_Xi_s(sa.F, 2)
+    polys = [X1, X1 + X2**3]
+    w, inp = batch.mimc_stark_unit(0, steps)
+    assert inp == c["inputs"] and ["%064x" % col[-1] for col in w] == c["outputs"]
+    flat = stark.prove_flat(b"".join(wire(col) for col in w), wire(inp), steps, ext, 2, polys)
+    assert len(flat) == c["proof_bytes"] and flat[:32].hex() == c["m_root"] and flat[32:64].hex() == c["l_root"]
+    assert hashlib.sha256(flat).hexdigest() == c["proof_sha256"]
+    assert stark.verify_flat(flat, wire(inp), b"".join(bytes.fromhex(v) for v in c["outputs"]), steps, ext, 2, polys)
+    # the device-resident path with witnesses generated on the device (what config 5 runs): unit 0 of a batch
+    pr = batch.StarkUnitProver(steps, ext, chunk=4)
+    try:
+        pr.generate(0, 4)
+        pr.prove(4)
+        assert pr.download(4)[0] == flat
+    finally:
+        pr.close()
+
+
 def test_stark_batch_units_and_device_api(sa, oracle):
     """batch.prove_stark_batch (config 5's unit as a full STARK) == the oracle per unit; and the device-resident entry
     point with its deferred constraint status."""
