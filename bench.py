@@ -276,8 +276,15 @@ def extras(dev, quick):
     # sustained figure, `ms_after_idle` one commit after 0.3 s of idling
     time.sleep(0.3)
     ms1 = dev.timed(lambda: dev.ck(L.sh_dev_merkelize(ctx, dx, n, 1, dt), "merkle"), 1)
+    root = ctypes.create_string_buffer(32)
+    dev.ck(L.sh_dev_download(ctx, ctypes.c_void_p(dt.value + 32), root, 32), "dl")
+    try:  # the root against the tree oracle/oracle.c hashed for the same leaves (tests/golden/merkle_large.json)
+        gold = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "merkle_large.json")))["cases"] if c["logn"] == logn and c["seed"] == 7]
+    except Exception:
+        gold = []
     out["merkelize_2^%d" % logn] = {"ms": round(ms, 4), "leaves_per_s": n / ms * 1e3,
-                                    "algorithmic_GBps": 64.0 * n / ms / 1e6, "ms_after_idle": round(ms1, 4)}
+                                    "algorithmic_GBps": 64.0 * n / ms / 1e6, "ms_after_idle": round(ms1, 4), "root": root.raw.hex(),
+                                    "matches_fixture": (root.raw.hex() == gold[0]["root"]) if gold else None}
     dev.free(dx)
     dev.free(dt)
     # ---- LDE: 2^16-step trace, 8x extension, 4 columns (stark.py:27-36 + 253-256) ---------------------------

@@ -8,6 +8,7 @@ reference cannot reach (BASELINE configs[3]).
     python3 tests/golden/generate_large.py          # writes tests/golden/ntt_large.json  (about 4 min, 4 GB)
     python3 tests/golden/generate_large.py --missing  # keeps the cases already in the file, adds the sizes it lacks
     python3 tests/golden/generate_large.py --fri      # writes tests/golden/fri_large.json (about 3 min, 3 GB): below
+    python3 tests/golden/generate_large.py --merkle   # writes tests/golden/merkle_large.json (about 1 min, 2 GB)
     python3 tests/golden/generate_large.py --stark [12 14 16]  # writes / extends tests/golden/stark_large.json: see stark_main
 
 2^17 is the domain of config 3's commit, whose default plan (9, 8) the reference-generated fixtures reach only through the
@@ -119,7 +120,32 @@ def stark_main():
                                     "pinned to the reference by stark.json)", "cases": cases}, fh, indent=1)
 
 
+def merkle_main():
+    """--merkle: the Merkle commitment bench.py times (2^24 leaves x_i = BLAKE2s(seed_le64 || i_le64) mod p, seed 7, and the 2^20-leaf
+    one of its --quick mode) hashed by oracle/oracle.c:or_merkelize (merkle_tree.py:36-56 with permute4): the root, three interior
+    nodes and the SHA-256 of the whole 2n x 32-byte node array (slot 0 = zeros, as sh_merkelize writes it)."""
+    out = os.path.join(HERE, "merkle_large.json")
+    cases = []
+    for logn in (20, 24):
+        n = 1 << logn
+        t0 = time.time()
+        leaves = b"".join((int.from_bytes(hashlib.blake2s(struct.pack("<QQ", 7, i)).digest(), "big") % P).to_bytes(32, "big")
+                          for i in range(n))
+        nodes = coracle.merkelize_bytes(leaves)
+        case = {"logn": logn, "n": n, "seed": 7, "root": nodes[32:64].hex(), "node_2": nodes[64:96].hex(), "node_n_minus_1": nodes[32 * (n - 1):32 * n].hex(),
+                "node_n": nodes[32 * n:32 * n + 32].hex(), "nodes_sha256": hashlib.sha256(bytes(32) + nodes[32:]).hexdigest(),
+                "oracle_seconds": round(time.time() - t0, 1)}
+        print(case, flush=True)
+        cases.append(case)
+        del leaves, nodes
+    with open(out, "w") as fh:
+        json.dump({"generator": "tests/golden/generate_large.py --merkle (oracle/oracle.c:or_merkelize, pinned to the reference by merkle.json)",
+                   "cases": cases}, fh, indent=1)
+
+
 def main():
+    if "--merkle" in sys.argv[1:]:
+        return merkle_main()
     if "--fri" in sys.argv[1:]:
         return fri_main()
     if "--stark" in sys.argv[1:]:

@@ -1003,6 +1003,40 @@ def test_full_size_merkle_2_24_branches_verify(sa):
         L.sh_dev_free(ctx, dt)
 
 
+@pytest.mark.parametrize("logn", [20, 24])
+def test_merkle_commit_at_size_vs_oracle_fixture(sa, logn):
+    """The Merkle commitment bench.py times (2^24 seeded leaves; 2^20 in its --quick mode): EVERY node of the tree against the tree
+    oracle/oracle.c hashed (tests/golden/merkle_large.json: root, three interior nodes, SHA-256 of all 2n nodes)."""
+    import ctypes
+    c = [c for c in load_golden("merkle_large.json")["cases"] if c["logn"] == logn][0]
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = 1 << logn
+    dx, dt = ctypes.c_void_p(), ctypes.c_void_p()
+    sa.lib.check(L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(dx)), "alloc")
+    sa.lib.check(L.sh_dev_alloc(ctx, 64 * n, ctypes.byref(dt)), "alloc")
+    try:
+        sa.lib.check(L.sh_dev_fill_seeded(ctx, dx, n, c["seed"]), "fill")
+        sa.lib.check(L.sh_dev_merkelize(ctx, dx, n, 1, dt), "merkelize")
+        h = hashlib.sha256()
+        step = 1 << 20  # nodes per download
+        buf = ctypes.create_string_buffer(32 * step)
+        first = None
+        for off in range(0, 2 * n, step):
+            sa.lib.check(L.sh_dev_download(ctx, ctypes.c_void_p(dt.value + 32 * off), buf, 32 * step), "download")
+            if first is None:
+                first = buf.raw[:96]
+            if off <= n - 1 < off + step:
+                assert buf.raw[32 * (n - 1 - off):32 * (n - off)].hex() == c["node_n_minus_1"]
+            if off <= n < off + step:
+                assert buf.raw[32 * (n - off):32 * (n - off) + 32].hex() == c["node_n"]
+            h.update(buf.raw)
+        assert first[:32] == bytes(32) and first[32:64].hex() == c["root"] and first[64:96].hex() == c["node_2"]
+        assert h.hexdigest() == c["nodes_sha256"]
+    finally:
+        L.sh_dev_free(ctx, dx)
+        L.sh_dev_free(ctx, dt)
+
+
 # ---- round 2: reference-independent pins for config 4, config 5 at its size, the new ABI entries -------------------------
 @pytest.mark.parametrize("logn", [17, 19, 21, 22, 23, 24])
 def test_ntt_large_digests_vs_oracle_fixture(sa, logn):
