@@ -367,11 +367,18 @@ def extras(dev, quick):
             dev.ck(L.sh_timer_stop(ctx, ctypes.byref(t)), "timer")
             best = t.value if best is None else min(best, t.value)
         dev.ck(L.sh_stark_status(ctx), "stark status")
-        head = ctypes.create_string_buffer(64)
-        dev.ck(L.sh_dev_download(ctx, dp, head, 64), "dl")
+        first = ctypes.create_string_buffer(plen)  # unit 0's flat proof: against the coefficient-form oracle's where a fixture exists
+        dev.ck(L.sh_dev_download(ctx, dp, first, plen), "dl")
+        sha = hashlib.sha256(first.raw).hexdigest()
+        try:
+            gold = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "stark_large.json")))["cases"]
+                    if c["steps"] == steps and c["ext"] == ext and c["unit"] == 0]
+        except Exception:
+            gold = []
         out["stark_prove_batch%d_steps_2^%d" % (bsz, logsteps)] = {
             "ms_per_batch": round(best, 4), "ms_per_proof": round(best / bsz, 5), "proofs_per_s": bsz / best * 1e3,
-            "proof_bytes": plen, "m_root": head.raw[:32].hex()}
+            "proof_bytes": plen, "m_root": first.raw[:32].hex(), "proof_sha256": sha,
+            "matches_fixture": (sha == gold[0]["proof_sha256"]) if gold else None}
         for p_ in (dw, di, dp):
             dev.free(p_)
     return out
