@@ -12,6 +12,16 @@ namespace {
 constexpr int TPB = 256;
 
 inline unsigned grid_for(uint64_t work, int tpb = TPB) { return (unsigned)((work + tpb - 1) / tpb); }
+// One thread per element of a vector of up to 2^32 elements (or a batch of that many): a launch holds fewer than 2^32 threads per grid
+// dimension, so from 2^30 threads on the blocks spread over blockIdx.y; flat_thread() is the element index either way.
+constexpr uint64_t FLAT_GRID_X = 1ull << 22;
+inline dim3 flat_grid_for(uint64_t work) {
+  const uint64_t blocks = (work + TPB - 1) / TPB;
+  return blocks <= FLAT_GRID_X ? dim3((unsigned)blocks) : dim3((unsigned)FLAT_GRID_X, (unsigned)((blocks + FLAT_GRID_X - 1) / FLAT_GRID_X));
+}
+__device__ __forceinline__ uint64_t flat_thread() {
+  return ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * TPB + threadIdx.x;
+}
 
 __device__ __forceinline__ void load8(const uint32_t* p, uint32_t w[8]) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -27,14 +37,14 @@ __device__ __forceinline__ void store8(uint32_t* p, const uint32_t w[8]) {
 
 // ---- conversions ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TPB) wire_to_limb_kernel(const uint32_t* wire, fp* limbs, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  uint64_t i = flat_thread();
   if (i >= n) return;
   uint32_t w[8];
   load8(wire + 8 * i, w);
   fp_store(limbs + i, fp_from_wire_words(w));  // may be >= p: limb form is lazily reduced
 }
 __global__ void __launch_bounds__(TPB) limb_to_wire_kernel(const fp* limbs, uint32_t* wire, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  uint64_t i = flat_thread();
   if (i >= n) return;
   uint32_t w[8];
   fp_to_wire_words(fp_canon(fp_load(limbs + i)), w);
@@ -42,7 +52,7 @@ __global__ void __launch_bounds__(TPB) limb_to_wire_kernel(const fp* limbs, uint
 }
 // x_i = BLAKE2s(seed_le64 || i_le64) mod p   (same generator as tests/golden/generate.py)
 __global__ void __launch_bounds__(TPB) fill_seeded_kernel(fp* out, uint64_t n, uint64_t seed) {
-  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  uint64_t i = flat_thread();
   if (i >= n) return;
   uint32_t m[16];
 #pragma unroll
@@ -75,12 +85,12 @@ __global__ void __launch_bounds__(64) fill_mimc_units_kernel(fp* wit, fp* inputs
   }
 }
 __global__ void __launch_bounds__(TPB) pointwise_mul_kernel(const fp* a, const fp* b, fp* out, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  uint64_t i = flat_thread();
   if (i >= n) return;
   fp_store(out + i, fp_mul(fp_load(a + i), fp_load(b + i)));
 }
 __global__ void __launch_bounds__(TPB) powers_kernel(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  uint64_t i = flat_thread();
   if (i >= n) return;
   fp v = fp_load(lo + (i & ((1ull << lb) - 1)));
   if (hi) v = fp_mul(v, fp_load(hi + (i >> lb)));
@@ -98,7 +108,7 @@ __global__ void __launch_bounds__(TPB) tw2_kernel(const fp* lo, const fp* hi, ui
   fp_store(out + g, v);
 }
 __global__ void __launch_bounds__(TPB) pad_copy_kernel(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint64_t total) {
-  uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  uint64_t g = flat_thread();
   if (g >= total) return;
   uint64_t b = g / n, i = g - b * n;
   fp_store(dst + g, i < n_in ? fp_load(src + b * n_in + i) : fp_zero());
@@ -519,18 +529,18 @@ __global__ void __launch_bounds__(TPB) fri_gather_all_kernel(FriSampleArgs a) {
 
 hipError_t shk_wire_to_limb(const uint8_t* d_wire, fp* d_limbs, uint64_t n, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(wire_to_limb_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, reinterpret_cast<const uint32_t*>(d_wire),
+  hipLaunchKernelGGL(wire_to_limb_kernel, flat_grid_for(n), dim3(TPB), 0, st, reinterpret_cast<const uint32_t*>(d_wire),
                      d_limbs, n);
   return hipGetLastError();
 }
 hipError_t shk_limb_to_wire(const fp* d_limbs, uint8_t* d_wire, uint64_t n, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(limb_to_wire_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, d_limbs, reinterpret_cast<uint32_t*>(d_wire), n);
+  hipLaunchKernelGGL(limb_to_wire_kernel, flat_grid_for(n), dim3(TPB), 0, st, d_limbs, reinterpret_cast<uint32_t*>(d_wire), n);
   return hipGetLastError();
 }
 hipError_t shk_fill_seeded(fp* d, uint64_t n, uint64_t seed, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(fill_seeded_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, d, n, seed);
+  hipLaunchKernelGGL(fill_seeded_kernel, flat_grid_for(n), dim3(TPB), 0, st, d, n, seed);
   return hipGetLastError();
 }
 hipError_t shk_fill_mimc_units(fp* wit, fp* inputs, uint64_t steps, uint32_t first_unit, uint32_t batch, uint32_t constant,
@@ -542,12 +552,12 @@ hipError_t shk_fill_mimc_units(fp* wit, fp* inputs, uint64_t steps, uint32_t fir
 }
 hipError_t shk_pointwise_mul(const fp* a, const fp* b, fp* out, uint64_t n, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(pointwise_mul_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, a, b, out, n);
+  hipLaunchKernelGGL(pointwise_mul_kernel, flat_grid_for(n), dim3(TPB), 0, st, a, b, out, n);
   return hipGetLastError();
 }
 hipError_t shk_powers(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint64_t n, hipStream_t st) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(powers_kernel, dim3(grid_for(n)), dim3(TPB), 0, st, lo, hi, lb, out, n);
+  hipLaunchKernelGGL(powers_kernel, flat_grid_for(n), dim3(TPB), 0, st, lo, hi, lb, out, n);
   return hipGetLastError();
 }
 hipError_t shk_tw2(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint32_t log_R, uint32_t log_S, hipStream_t st) {
@@ -558,7 +568,7 @@ hipError_t shk_tw2(const fp* lo, const fp* hi, uint32_t lb, fp* out, uint32_t lo
 hipError_t shk_pad_copy(const fp* src, fp* dst, uint64_t n_in, uint64_t n, uint32_t batch, hipStream_t st) {
   const uint64_t total = n * batch;
   if (!total) return hipSuccess;
-  hipLaunchKernelGGL(pad_copy_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, src, dst, n_in, n, total);
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid_for(total), dim3(TPB), 0, st, src, dst, n_in, n, total);
   return hipGetLastError();
 }
 // the serial levels L .. 1 -> 0 of a tree: as few launches as 8 levels per launch allow, the levels dealt evenly

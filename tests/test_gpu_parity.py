@@ -8,7 +8,7 @@ import struct
 
 import pytest
 
-from conftest import load_golden, GOLDEN
+from conftest import load_golden, GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -407,9 +407,53 @@ def test_full_size_ntt_2_24_roundtrip(sa):
     assert L.sh_dev_free(ctx, dx) == 0 and L.sh_dev_free(ctx, dy) == 0
 
 
-@pytest.mark.parametrize("logsteps", [16, 20])
+def _max_sizes_tool():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("max_sizes", os.path.join(ROOT, "tools", "max_sizes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("logn", [25, 27])
+def test_transforms_above_the_bench_size(sa, logn):
+    """Maximum sizes (the library takes orders up to 2^32, include/starkhip.h): four-pass plans, 1 and 4 GiB vectors, checked without the
+    oracle through the definition -- 1024 outputs exactly from the residue-class sums of the dense input, the inverse on every element,
+    and sampled outputs moving by sum_k d_k w^(j p_k) when K coefficients change (tools/max_sizes.py; 2^28 .. 2^32 points and the
+    2^28 / 2^30-leaf trees run there: profiles/r05_max_sizes.txt)."""
+    ms = _max_sizes_tool()
+    assert ms.check_transform(ms.Dev(), logn, random.Random(logn))
+
+
+def test_merkle_tree_above_the_bench_size(sa):
+    """2^26 leaves (4 GiB of nodes): leaf, siblings and root of 64 branches recomputed with hashlib."""
+    ms = _max_sizes_tool()
+    assert ms.check_merkle(ms.Dev(), 26, random.Random(26), full=False)
+
+
+def test_per_element_launches_beyond_2_30_threads(sa):
+    """A launch holds fewer than 2^32 threads per grid dimension: the per-element kernels (conversions, seeded fill, pointwise product,
+    padding copy) spread their blocks over blockIdx.y from 2^30 threads on (kernels.hip:flat_grid_for) -- a 2^32-element fill failed
+    with `invalid configuration argument` before.  Here: 2^30 + 2^20 elements (32 GiB), the values either side of the seam."""
+    import ctypes
+    L, ctx = sa.lib.lib(), sa.lib.ctx()
+    n = (1 << 30) + (1 << 20)
+    d = ctypes.c_void_p()
+    sa.lib.check(L.sh_dev_alloc(ctx, 32 * n, ctypes.byref(d)), "alloc")
+    try:
+        sa.lib.check(L.sh_dev_fill_seeded(ctx, d, n, 31), "fill")
+        b = ctypes.create_string_buffer(32 * 4)
+        for i in (0, (1 << 30) - 2, (1 << 30) + 777, n - 4):
+            sa.lib.check(L.sh_dev_to_wire(ctx, ctypes.c_void_p(d.value + 32 * i), b, 4), "to_wire")
+            assert b.raw == wire([seeded(31, i + k) for k in range(4)])
+    finally:
+        L.sh_dev_free(ctx, d)
+
+
+@pytest.mark.parametrize("logsteps", [16, 20, 22])
 def test_full_size_fri_prove_then_verify(sa, logsteps):
-    """Config 5's proof size (2^16 steps, N = 2^19) and the metric's 2^20-step trace (N = 2^23): the GPU proof is
+    """Config 5's proof size (2^16 steps, N = 2^19), the metric's 2^20-step trace (N = 2^23) and the LARGEST commit the reference's
+    index sampling allows (2^22 steps, N = 2^25: utils.py:69 asserts N/4 < 2^24): the GPU proof is
     accepted by the host verifier (fri.py:268-366 semantics), and a corrupted one is rejected."""
     import ctypes
     L, ctx = sa.lib.lib(), sa.lib.ctx()
