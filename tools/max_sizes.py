@@ -185,6 +185,32 @@ def check_transform_in_place(dev, logn, rng):
     return ok_fill and ok_a and ok_b and ok_c
 
 
+def check_host_api(dev, logn):
+    """sh_ntt from and to caller (pageable) buffers of more than 4 GiB: staged through the pinned slots, the same bytes as the device
+    API's result"""
+    n = 1 << logn
+    wb = root_of(n).to_bytes(32, "big")
+    t0 = time.time()
+    dx, dy = dev.alloc(32 * n), dev.alloc(32 * n)
+    dev.ck(dev.L.sh_dev_fill_seeded(dev.ctx, dx, n, 0xabcd), "fill")
+    dev.ck(dev.L.sh_dev_ntt(dev.ctx, dx, dy, n, 1, wb, 0), "ntt")
+    x, y, y2 = (ctypes.create_string_buffer(32 * n) for _ in range(3))
+    ch = 1 << 24
+    for off in range(0, n, ch):
+        for d, h in ((dx, x), (dy, y)):
+            dev.ck(dev.L.sh_dev_to_wire(dev.ctx, ctypes.c_void_p(d.value + 32 * off),
+                                        ctypes.cast(ctypes.addressof(h) + 32 * off, ctypes.c_void_p), min(ch, n - off)), "dl")
+    dev.free(dx)
+    dev.free(dy)
+    t1 = time.time()
+    dev.ck(dev.L.sh_ntt(dev.ctx, x, n, y2, n, wb, 0), "sh_ntt")
+    t_h = time.time() - t1
+    same = hashlib.sha256(y).digest() == hashlib.sha256(y2).digest()
+    print("sh_ntt from / to pageable host buffers, 2^%d points (%d GiB each way): %.2f s, same bytes as the device API %s | %.0f s"
+          % (logn, (32 * n) >> 30, t_h, same, time.time() - t0), flush=True)
+    return same
+
+
 def blake(b):
     return hashlib.blake2s(b).digest()
 
@@ -301,6 +327,7 @@ def main():
     ap.add_argument("--merkle-logs", type=int, nargs="*", default=[25, 26, 28])
     ap.add_argument("--full-merkle-log", type=int, default=25)
     ap.add_argument("--in-place-logs", type=int, nargs="*", default=[], help="e.g. 32: the vector alone is 128 GiB")
+    ap.add_argument("--host-logs", type=int, nargs="*", default=[], help="e.g. 28: sh_ntt on 8 GiB host buffers")
     ap.add_argument("--no-fri", action="store_true")
     ap.add_argument("--seed", type=int, default=5)
     args = ap.parse_args()
@@ -315,6 +342,8 @@ def main():
         ok = check_merkle(dev, logn, rng, full=logn <= args.full_merkle_log) and ok
     if not args.no_fri:
         ok = check_fri_max(dev) and ok
+    for logn in args.host_logs:
+        ok = check_host_api(dev, logn) and ok
     print("ALL OK" if ok else "MISMATCH", flush=True)
     return 0 if ok else 1
 
