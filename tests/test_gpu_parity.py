@@ -844,13 +844,14 @@ def test_stark_shape_errors(sa):
         stark.prove_flat(wire([1] * 8), wire([1]), 8, 8, 1, [X**9])
 
 
-@pytest.mark.parametrize("logsteps", [10, 14, 16, 20])
-def test_stark_large_prove_then_verify(sa, oracle, logsteps):
+@pytest.mark.parametrize("logsteps,ext", [(10, 8), (14, 8), (16, 8), (20, 8), (14, 4), (14, 16), (12, 32), (18, 4), (16, 16)])
+def test_stark_large_prove_then_verify(sa, oracle, logsteps, ext):
     """Sizes the coefficient-form oracle cannot reach: prove on the device, verify with the host verifier and with the
-    oracle's restated verifier (transition + boundary identities at 80 positions, FRI on the linear combination)."""
+    oracle's restated verifier (transition + boundary identities at 80 positions, FRI on the linear combination).  Extension
+    factors 4 (the smallest a cubic step admits: deg C (X - x_last) = 3 steps - 2 must stay below steps * ext), 8, 16, 32."""
     from starks_amd import stark
     from starks_amd.multivariate_polynomial import generate_Xi_s
-    steps, ext = 1 << logsteps, 8
+    steps = 1 << logsteps
     X1, X2 = generate_Xi_s(sa.F, 2)
     polys = [X1, X1 + X2**3]
     sp = [{(1, 0): 1}, {(1, 0): 1, (0, 3): 1}]
