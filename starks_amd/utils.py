@@ -9,12 +9,21 @@ from .wireseq import WireList
 
 
 def get_power_cycle(r, field):
-    """utils.py:30-38: [1, r, r^2, ...] until the powers return to 1."""
-    if int(field.p) != MIMC_P:
-        raise NotImplementedError("starks_amd accelerates the MiMC prime field only")
-    n = _lib.order_of_root(r)
+    """utils.py:30-38: [1, r, r^2, ...] until the powers return to 1.  The MiMC field with a root of power-of-two order -- every
+    domain of the proving path (stark.py:223, fri.py:211) -- on the GPU; another field or order (the reference's unit test walks a
+    6th root of unity mod 31, test_utils.py:20-30) is outside the hot path and walked here as the reference walks it (orders up to
+    2^12, like fft._host_dft)."""
+    n = _lib.order_of_root(r) if int(field.p) == MIMC_P else None
     if n is None:
-        raise NotImplementedError("r must have power-of-two order")
+        r = field(r)
+        out, one = [field(1)], field(1)
+        while True:
+            nxt = out[-1] * r
+            if nxt == one:
+                return out
+            if len(out) >= 1 << 12:
+                raise NotImplementedError("host power cycle: order above 2^12 (use a power-of-two order in the MiMC field on the GPU)")
+            out.append(nxt)
     out = ctypes.create_string_buffer(32 * n)
     _lib.check(_lib.lib().sh_power_cycle(_lib.ctx(), int(r).to_bytes(32, "big"), n, out), "sh_power_cycle")
     return WireList(out.raw, field)  # lazy: elements are created on index / iteration (wireseq.py)

@@ -287,6 +287,14 @@ def test_host_generality_outside_the_hot_path():
             for j, y in enumerate(b):
                 prod[(i + j) % order] = (prod[(i + j) % order] + x * y) % 31
         assert got == [(order * v) % 31 for v in prod]   # n * (a * b): the reference omits the 1/n (fft.py:345)
+    # get_power_cycle in another field (test_utils.py:20-30 walks a 6th root of unity mod 31), and of an odd order in the MiMC field
+    from starks_amd.utils import get_power_cycle
+    assert get_power_cycle(F(3) ** 5, F) == [1, 26, 25, 30, 5, 6]
+    P = 2**256 - 2**32 * 351 + 1
+    Fp = IntegersModP(P)
+    g5 = Fp(7) ** ((P - 1) // 5)  # 5 divides p - 1 = 2^32 (2^224 - 351)
+    cyc = get_power_cycle(g5, Fp)
+    assert len(cyc) == 5 and int(cyc[4]) * int(g5) % P == 1
 
 
 def test_proof_stream_round_trips_on_random_shapes():
