@@ -14,6 +14,7 @@
 #include "../../include/starkhip.h"
 #include "blake2s.cuh"
 #include "fp256.cuh"
+#include "internal.hpp"  // SHK_STARK_MAX_WIDTH, SHK_STARK_MAX_TERMS: the prover's limits are the verifier's
 
 namespace {
 
@@ -140,6 +141,9 @@ int fri_verify(Cursor cur, const uint8_t merkle_root_in[32], uint64_t n, const f
     const uint32_t lg = (uint32_t)ilog2u(roudeg), l2 = lg - 1, l1 = lg + 1;
     const uint8_t* root2 = cur.take(32);
     if (!root2) return SH_ERR_INVALID;
+    // the round's branches must all be there before anything is derived from `s` (a hostile count must cost nothing: the sampling
+    // below hashes 4 s bytes of entropy)
+    if (cur.left / (32ull * (l2 + 4ull * l1)) < s) return SH_ERR_INVALID;
     const fp special_x = f_from_wire(merkle_root);  // field(m[1]) (fri.py:229)
     if (!sample_indices(root2, q, s, exclude, &ys)) return SH_ERR_INVALID;
     const fp inv_i = f_pow(w, 3 * q);  // I^-1 = I^3
@@ -168,8 +172,9 @@ int fri_verify(Cursor cur, const uint8_t merkle_root_in[32], uint64_t n, const f
   // the final layer (fri.py:340-366): its Merkle root is the last committed root, and the values off the first maxdeg_plus_1 points
   // lie on the interpolant through those
   const uint64_t len = roudeg;
+  if (len < 4 || len > cur.left / 32) return SH_ERR_INVALID;  // (before 32 * len: no wrap-around)
   const uint8_t* data = cur.take(32 * len);
-  if (!data || cur.left != 0 || len < 4) return SH_ERR_INVALID;
+  if (!data || cur.left != 0) return SH_ERR_INVALID;
   {
     std::vector<uint8_t> nodes(64 * len, 0);
     const uint64_t q = len / 4;
@@ -232,6 +237,7 @@ extern "C" {
 int sh_fri_verify(const uint8_t* proof, uint64_t proof_len, const uint8_t merkle_root[32], uint64_t n, const uint8_t root[32],
                   uint64_t maxdeg_plus_1, uint32_t exclude_multiples_of, uint32_t samples) {
   if (!proof || !merkle_root || !root || n < 4 || (n & (n - 1)) || samples == 0) return SH_ERR_INVALID;
+  if (n > (1ull << 32)) return SH_ERR_UNSUPPORTED;  // the field has no root of a larger power-of-two order
   const fp w = f_from_wire(root);
   if (!f_eq(f_pow(w, n / 2), fp_neg(fp_one()))) return SH_ERR_ROOT_ORDER;
   return fri_verify(Cursor{proof, proof_len}, merkle_root, n, w, maxdeg_plus_1, exclude_multiples_of, samples);
@@ -240,16 +246,20 @@ int sh_fri_verify(const uint8_t* proof, uint64_t proof_len, const uint8_t merkle
 int sh_stark_verify(const uint8_t* proof, uint64_t proof_len, const uint8_t* inputs, const uint8_t* outputs, uint64_t steps, uint32_t ext,
                     uint32_t width, const uint8_t* term_coefs, const uint8_t* term_exps, const uint32_t* term_counts, uint32_t samples) {
   if (!proof || !inputs || !outputs || !term_coefs || !term_exps || !term_counts || width == 0 || samples == 0) return SH_ERR_INVALID;
-  if (steps < 2 || (steps & (steps - 1)) || ext < 2 || (ext & (ext - 1)) || steps * ext >= (1ull << 24)) return SH_ERR_INVALID;
+  if (steps < 2 || (steps & (steps - 1)) || ext < 2 || (ext & (ext - 1))) return SH_ERR_INVALID;
+  if (steps >= (1ull << 24) || ext >= (1u << 24) || steps * ext >= (1ull << 24)) return SH_ERR_INVALID;  // utils.py:69 (no wrap-around)
+  if (width > SHK_STARK_MAX_WIDTH) return SH_ERR_UNSUPPORTED;  // as sh_stark_prove (capi.hip:stark_terms)
   const uint64_t n = steps * ext;
   const uint32_t lg = (uint32_t)ilog2u(n), k = 3 * width;
   uint32_t degree = 0, begin = 0;
   std::vector<uint32_t> tbegin(width + 1, 0);
   for (uint32_t d = 0; d < width; ++d) {
     tbegin[d] = begin;
+    if (term_counts[d] > SHK_STARK_MAX_TERMS) return SH_ERR_UNSUPPORTED;
     begin += term_counts[d];
   }
   tbegin[width] = begin;
+  if (begin == 0 || begin > SHK_STARK_MAX_TERMS) return begin ? SH_ERR_UNSUPPORTED : SH_ERR_INVALID;
   std::vector<fp> coef(begin);
   for (uint32_t t = 0; t < begin; ++t) {
     coef[t] = f_from_wire(term_coefs + 32 * t);
@@ -262,6 +272,7 @@ int sh_stark_verify(const uint8_t* proof, uint64_t proof_len, const uint8_t* inp
   const uint8_t* l_root = cur.take(32);
   if (!m_root || !l_root) return SH_ERR_INVALID;
   const uint64_t pb = 32ull * (2 * k + (lg - 1)), lb = 32ull * (lg + 1);
+  if (cur.left / (2 * pb + lb) < samples) return SH_ERR_INVALID;  // (before the product: no wrap-around)
   const uint8_t* branches = cur.take((2 * pb + lb) * samples);
   if (!branches) return SH_ERR_INVALID;
   const fp g2 = h_root_pow2((int)lg);

@@ -104,3 +104,53 @@ def test_stark_verifier_native_vs_python(c):
     k0 = sorted(other[-1])[0]
     other[-1][k0] = (other[-1][k0] + 1) % P
     assert _decide(lambda: stark.verify_flat(flat, inb, wire(outs), c["steps"], c["ext"], c["width"], [_Poly(d) for d in other])) is False
+
+
+def test_verifiers_survive_hostile_arguments(tmp_path):
+    """The C entries take lengths and counts from the caller: whatever they are (zero, 2^32 - 1 samples, a domain of 2^63 points,
+    products that wrap around 64 bits, term counts of 2^31, buffers shorter than the counts imply) the answer is an error code,
+    at once -- no read past the buffer, no allocation sized by an unchecked count, no exception across the C ABI.  (Round 5's
+    first fuzz run hung in the index sampling of a 12 kB proof declared to hold 2^32 - 1 samples.)  Run in a child process so
+    that a crash or a hang fails the test instead of the suite."""
+    import subprocess
+    import sys
+    import textwrap
+    from conftest import ROOT
+    code = textwrap.dedent("""
+        import sys, random, ctypes
+        sys.path.insert(0, %r)
+        from starks_amd import _lib
+        L = _lib.lib()
+        rng = random.Random(1)
+        P = _lib.MIMC_P
+        seen = set()
+        for it in range(3000):
+            n = rng.choice([0, 1, 2, 3, 4, 8, 16, 64, 256, 1 << 10, 1 << 20, 1 << 25, 1 << 32, 1 << 40, 1 << 63, (1 << 64) - 1, rng.randrange(1 << 20)])
+            md = rng.choice([0, 1, 4, 16, 17, 64, 256, 1 << 20, 1 << 62, (1 << 64) - 1, rng.randrange(1, 1 << 12)])
+            ex = rng.choice([0, 1, 2, 3, 8, 16, 255, (1 << 32) - 1])
+            sm = rng.choice([0, 1, 5, 40, 80, 1000, (1 << 32) - 1])
+            plen = rng.choice([0, 1, 31, 32, 33, 64, 1000, 4096, rng.randrange(1 << 16)])
+            buf = bytes(rng.randrange(256) for _ in range(min(plen, 512))) + bytes(max(0, plen - 512))
+            ok_n = n and n & (n - 1) == 0 and n <= 1 << 32
+            w = (pow(7, (P - 1) // n, P) if ok_n and rng.random() < 0.7 else rng.randrange(P)).to_bytes(32, "big")
+            seen.add(L.sh_fri_verify(buf, len(buf), bytes(32), n, w, md, ex, sm))
+        for it in range(3000):
+            steps = rng.choice([0, 1, 2, 3, 4, 8, 64, 1 << 16, 1 << 20, 1 << 24, 1 << 40, 1 << 63, (1 << 64) - 1])
+            ext = rng.choice([0, 1, 2, 3, 4, 8, 16, 1 << 20, 1 << 24, 1 << 31, (1 << 32) - 1])
+            width = rng.choice([0, 1, 2, 3, 9, 10, 100, (1 << 32) - 1])
+            sm = rng.choice([0, 1, 80, 1000, (1 << 32) - 1])
+            plen = rng.choice([0, 1, 63, 64, 65, 1000, rng.randrange(1 << 16)])
+            buf = bytes(rng.randrange(256) for _ in range(min(plen, 512))) + bytes(max(0, plen - 512))
+            wd = min(width, 12)
+            nterms = [rng.choice([0, 1, 2, 5, 1 << 31, (1 << 32) - 1]) for _ in range(max(1, wd))]
+            tot = min(sum(t for t in nterms if t < 100), 64)
+            coefs = bytes(32 * max(1, tot))
+            exps = bytes(rng.randrange(8) for _ in range(max(1, tot) * (wd + 1)))
+            counts = (ctypes.c_uint32 * len(nterms))(*nterms)
+            seen.add(L.sh_stark_verify(buf, len(buf), bytes(32 * max(1, wd)), bytes(32 * max(1, wd)), steps, ext, width, coefs, exps, counts, sm))
+        assert 0 not in seen, seen
+        print("codes", sorted(seen))
+    """ % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "codes" in out.stdout
