@@ -427,6 +427,23 @@ def callsite_times(quick):
     ms, proof = best(lambda: fri.prove_low_degree(poly, F(g2), steps, exclude_multiples_of=8))
     res["prove_low_degree_2^%d_ms" % (steps.bit_length() - 1)] = round(ms, 3)
     ok = ok and len(proof[-1]) == 128
+    # STARK.mk_proof / verify_proof (stark.py:233-279, 281-388) as a user of the reference calls them: the witness a list of Python ints
+    # per state variable (generated here by the step polynomials, untimed), the proof the reference's nested list
+    from starks_amd import stark
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    X1, X2 = generate_Xi_s(F, 2)
+    wit = [[0] * steps, [0] * steps]
+    a, b = 42, 3
+    for i in range(steps):
+        wit[0][i], wit[1][i] = a, b
+        a, b = a, (a + b * b * b) % P
+    S = stark.STARK(F, steps, 8, 2, [X1, X1 + X2**3])
+    boundary = [(0, 0, 42), (0, 1, 3)]
+    ms, pr = best(lambda: S.mk_proof(wit, boundary))
+    res["mk_proof_2^%d_from_python_lists_ms" % (steps.bit_length() - 1)] = round(ms, 3)
+    ms, good = best(lambda: S.verify_proof(pr, wit, boundary))
+    res["verify_proof_2^%d_ms" % (steps.bit_length() - 1)] = round(ms, 3)
+    ok = ok and bool(good) and len(pr) == 4
     res["checks_ok"] = bool(ok)
     res["note"] = ("end to end per call: conversion + PCIe from pageable memory + GPU; *_from_a_python_list = a first call whose input is "
                    "a list of Python ints; the others take the wire-backed output of an earlier stage (starks_amd/wireseq.py)")
