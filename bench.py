@@ -443,7 +443,9 @@ def callsite_times(quick):
     res["mk_proof_2^%d_from_python_lists_ms" % (steps.bit_length() - 1)] = round(ms, 3)
     ms, good = best(lambda: S.verify_proof(pr, wit, boundary))
     res["verify_proof_2^%d_ms" % (steps.bit_length() - 1)] = round(ms, 3)
-    ok = ok and bool(good) and len(pr) == 4
+    ms, good2 = best(lambda: S.verify_proof_native(pr, wit, boundary))
+    res["verify_proof_native_2^%d_ms" % (steps.bit_length() - 1)] = round(ms, 3)
+    ok = ok and bool(good) and bool(good2) and len(pr) == 4
     res["checks_ok"] = bool(ok)
     res["note"] = ("end to end per call: conversion + PCIe from pageable memory + GPU; *_from_a_python_list = a first call whose input is "
                    "a list of Python ints; the others take the wire-backed output of an earlier stage (starks_amd/wireseq.py)")

