@@ -172,6 +172,13 @@ __device__ __forceinline__ void leaf_elem(const StarkArgs& a, uint64_t b, uint32
 // WIDE: the launch fills the chip several times over and the hashes use the asm rounds (blake2s.cuh); a narrow launch (one small proof),
 // where a wave per SIMD walks its compressions alone, keeps the C++ rounds (2.3 against ~4.5 us per compression there).
 constexpr uint64_t STARK_WIDE_THREADS = 1ull << 19;
+#ifndef SHK_STARK_SPLIT_LOG
+#define SHK_STARK_SPLIT_LOG 17
+#endif
+// rows (times batch) up to which a row of the quotient + leaf kernel is shared by two lanes, and one of the linear combination by four
+// (measured: two lanes pay up to 2^17 rows -- one 2^16-step proof --, four up to 2^16; profiles/r05_stark_narrow_lanes_ab.txt)
+constexpr uint64_t STARK_SPLIT_ROWS = SHK_STARK_SPLIT_LOG ? 1ull << SHK_STARK_SPLIT_LOG : 0;
+constexpr uint64_t STARK_SPLIT4_ROWS = SHK_STARK_SPLIT_LOG ? 1ull << (SHK_STARK_SPLIT_LOG - 1) : 0;
 
 // ---- D, B off the trace points (B everywhere but x = 1, x = x_last) and the packed leaves, in ONE pass -------------------------------
 // One thread per permute4 row: it computes the quotients of its four points, stores them (the linear combination reads them later) and
@@ -198,58 +205,65 @@ struct QuotientPoint {  // what the quotients of one domain point keep in regist
     for (int v = 0; v < W; ++v) P[v] = fp_load(pe + (uint64_t)v * N + pt);
   }
 };
+// the hash of the leaf pair (leaf A = point i + 2 s q, leaf B = point i + (2 s + 1) q) of permute4 row i, its quotients computed and stored
+// on the way
+template <int W, bool WIDE>
+__device__ __forceinline__ void quotient_leaf_pair(const StarkArgs& a, const fp* pe, uint64_t b, uint64_t i, int s, uint32_t h[8]) {
+  const uint64_t N = a.n, q = N >> 2;
+  constexpr uint32_t k = 3 * W;
+  b2_init(h);
+  const uint64_t la = i + (uint64_t)(2 * s) * q, lb = i + (uint64_t)(2 * s + 1) * q;
+  QuotientPoint<W> pt;
+  pt.load(a, pe, la);
+#pragma unroll 1
+  for (uint32_t blk = 0; blk < k; ++blk) {
+    uint32_t m[16];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const uint32_t e = 2 * blk + half;
+      if (e == k) pt.load(a, pe, lb);  // the message passes from leaf A to leaf B (uniform over the workgroup)
+      const uint32_t ee = e < k ? e : e - k, kind = ee / W, c = ee - kind * W;
+      const uint64_t col = (b * W + c) * N;
+      fp val;
+      if (kind == 0) {
+        val = fp_load(pe + (uint64_t)c * N + pt.i);  // (P[c] with a dynamic c: an L1 hit instead of a register-array index)
+      } else if (kind == 1) {
+        if (!pt.on_trace) {  // off the trace points: D = (P_c(g1 x) - step_c(P(x))) (x - r) / (x^s - 1)
+          const fp nxt = fp_load(pe + (uint64_t)c * N + pt.inext), fz = fp_load(a.fz + pt.i);  // requested before the products
+          const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], pt.P);
+          val = fp_mul(fp_sub(nxt, acc), fz);
+          fp_store(a.d_work + col + pt.i, val);
+        } else {
+          val = fp_load(a.d_work + col + pt.i);  // stark_trace_points_kernel's
+        }
+      } else {
+        if (!pt.special) {
+          const fp pc = fp_load(pe + (uint64_t)c * N + pt.i), x = fp_load(a.xpow + pt.i), wz = fp_load(a.inv_z2 + pt.i);
+          const fp* ab = a.iab + 3 * (b * W + c);  // a, (b, b 2^128)
+          const fp interp = fp_add(fp_load(ab), fp_mul2(x, fp2_load(reinterpret_cast<const fp2*>(ab + 1))));
+          val = fp_mul(fp_sub(pc, interp), wz);
+          fp_store(a.b_work + col + pt.i, val);
+        } else {
+          val = fp_load(a.b_work + col + pt.i);
+        }
+      }
+      fp_to_wire_words(fp_canon(val), m + 8 * half);
+    }
+    b2_compress<WIDE>(h, m, 64 * (blk + 1), blk + 1 == k);
+  }
+}
 template <int W, bool WIDE>
 __global__ void __launch_bounds__(TPB, (W <= 3 ? 4 : 1)) stark_quotients_leaves_kernel(StarkArgs a, uint32_t* nodes) {
   const uint64_t N = a.n, q = N >> 2;
   const uint64_t i = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   const uint64_t b = blockIdx.y;
   if (i >= q) return;
-  constexpr uint32_t k = 3 * W;
   const fp* pe = a.p_evals + b * W * N;
   uint32_t* tree = nodes + b * 2 * N * 8;
   b2digest d[2];
 #pragma unroll 1
   for (int s = 0; s < 2; ++s) {
-    b2_init(d[s].h);
-    const uint64_t la = i + (uint64_t)(2 * s) * q, lb = i + (uint64_t)(2 * s + 1) * q;
-    QuotientPoint<W> pt;
-    pt.load(a, pe, la);
-#pragma unroll 1
-    for (uint32_t blk = 0; blk < k; ++blk) {
-      uint32_t m[16];
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const uint32_t e = 2 * blk + half;
-        if (e == k) pt.load(a, pe, lb);  // the message passes from leaf A to leaf B (uniform over the workgroup)
-        const uint32_t ee = e < k ? e : e - k, kind = ee / W, c = ee - kind * W;
-        const uint64_t col = (b * W + c) * N;
-        fp val;
-        if (kind == 0) {
-          val = fp_load(pe + (uint64_t)c * N + pt.i);  // (P[c] with a dynamic c: an L1 hit instead of a register-array index)
-        } else if (kind == 1) {
-          if (!pt.on_trace) {  // off the trace points: D = (P_c(g1 x) - step_c(P(x))) (x - r) / (x^s - 1)
-            const fp nxt = fp_load(pe + (uint64_t)c * N + pt.inext), fz = fp_load(a.fz + pt.i);  // requested before the products
-            const fp acc = eval_terms<W>(a.term_coef, a.term_exps, a.term_begin[c], a.term_begin[c + 1], pt.P);
-            val = fp_mul(fp_sub(nxt, acc), fz);
-            fp_store(a.d_work + col + pt.i, val);
-          } else {
-            val = fp_load(a.d_work + col + pt.i);  // stark_trace_points_kernel's
-          }
-        } else {
-          if (!pt.special) {
-            const fp pc = fp_load(pe + (uint64_t)c * N + pt.i), x = fp_load(a.xpow + pt.i), wz = fp_load(a.inv_z2 + pt.i);
-            const fp* ab = a.iab + 3 * (b * W + c);  // a, (b, b 2^128)
-            const fp interp = fp_add(fp_load(ab), fp_mul2(x, fp2_load(reinterpret_cast<const fp2*>(ab + 1))));
-            val = fp_mul(fp_sub(pc, interp), wz);
-            fp_store(a.b_work + col + pt.i, val);
-          } else {
-            val = fp_load(a.b_work + col + pt.i);
-          }
-        }
-        fp_to_wire_words(fp_canon(val), m + 8 * half);
-      }
-      b2_compress<WIDE>(d[s].h, m, 64 * (blk + 1), blk + 1 == k);
-    }
+    quotient_leaf_pair<W, WIDE>(a, pe, b, i, s, d[s].h);
     store8(tree + (N / 2 + 2 * i + s) * 8, d[s].h);
   }
   b2digest top = b2_hash_pair<WIDE>(d[0].h, d[1].h);
@@ -257,6 +271,32 @@ __global__ void __launch_bounds__(TPB, (W <= 3 ? 4 : 1)) stark_quotients_leaves_
   if (i == 0) {
     uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     store8(tree, z);
+  }
+}
+// A narrow launch (one small proof: fewer rows than the chip has lanes) is a latency chain of 4 W + 1 compressions and 16 W products per
+// row: here TWO adjacent lanes share a row, one leaf pair each (2 W compressions, 8 W products), and the even lane hashes the parent
+// from its neighbour's digest (a lane swap inside the wave).  Same stores, same bytes.
+template <int W>
+__global__ void __launch_bounds__(TPB) stark_quotients_leaves_narrow_kernel(StarkArgs a, uint32_t* nodes) {
+  const uint64_t N = a.n, q = N >> 2;
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  const uint64_t i = g >> 1, b = blockIdx.y;
+  const int s = (int)(g & 1);
+  if (i >= q) return;  // both lanes of a row leave together (TPB is even)
+  const fp* pe = a.p_evals + b * W * N;
+  uint32_t* tree = nodes + b * 2 * N * 8;
+  b2digest own, other;
+  quotient_leaf_pair<W, false>(a, pe, b, i, s, own.h);
+  store8(tree + (N / 2 + 2 * i + s) * 8, own.h);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) other.h[w] = (uint32_t)__shfl_xor((int)own.h[w], 1);
+  if (s == 0) {
+    const b2digest top = b2_hash_pair<false>(own.h, other.h);
+    store8(tree + (N / 4 + i) * 8, top.h);
+    if (i == 0) {
+      uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      store8(tree, z);
+    }
   }
 }
 
@@ -304,6 +344,35 @@ __global__ void __launch_bounds__(64) stark_scalars_kernel(const uint32_t* mnode
 // stores the four values and hashes them on the spot -- the tree's leaf pass no longer reads l back, and its hashing runs in
 // the shadow of this kernel's memory traffic (the combination alone is HBM-bound).  nodes: [batch][2n] x 32 B as in
 // kernels.hip (the leaf level itself is not materialised: the branch gather re-derives leaves from l).
+// l at point x of proof b: sum_j alpha_j D_j + (alpha_j beta) P_j + (alpha_j gamma) B_j, the scalars as fp_mul2 pairs from LDS
+template <int W, class ScPair>
+__device__ __forceinline__ fp lincomb_point(const StarkArgs& a, uint64_t b, uint64_t x, uint32_t width, ScPair&& sc_pair) {
+  const uint64_t N = a.n;
+  fp acc = fp_zero();
+  if constexpr (W != 0) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      // the three values of a column are requested together, before their products (whose inline asm would otherwise pin
+      // every load right in front of its use)
+      const uint64_t col = (b * W + j) * N + x;
+      const fp v0 = fp_load(a.d_work + col), v1 = fp_load(a.p_evals + col), v2 = fp_load(a.b_work + col);
+      asm volatile("" ::: "memory");  // one scalar pair in registers at a time
+      acc = fp_add(acc, fp_mul2(v0, sc_pair(3u * j)));
+      asm volatile("" ::: "memory");
+      acc = fp_add(acc, fp_mul2(v1, sc_pair(3u * j + 1)));
+      asm volatile("" ::: "memory");
+      acc = fp_add(acc, fp_mul2(v2, sc_pair(3u * j + 2)));
+    }
+  } else {
+    for (uint32_t j = 0; j < width; ++j) {
+      const uint64_t col = (b * width + j) * N + x;
+      acc = fp_add(acc, fp_mul2(fp_load(a.d_work + col), sc_pair(3 * j)));
+      acc = fp_add(acc, fp_mul2(fp_load(a.p_evals + col), sc_pair(3 * j + 1)));
+      acc = fp_add(acc, fp_mul2(fp_load(a.b_work + col), sc_pair(3 * j + 2)));
+    }
+  }
+  return acc;
+}
 template <int W, bool WIDE>  // W = the width when it is 1 or 2 (all values of a point are requested before the first product), else 0
 __global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, const fp* scal, fp* l_evals, uint32_t* nodes) {
   // the proof's 3 * width scalar pairs, staged in LDS once per workgroup (kept in registers they would cost 16 VGPRs each)
@@ -332,29 +401,7 @@ __global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, 
   for (int r = 0; r < 4; ++r) {
     asm volatile("" ::: "memory");  // the scalar pairs are re-read from LDS every round, not kept live across the loop
     const uint64_t x = i + (uint64_t)r * q;
-    fp acc = fp_zero();
-    if constexpr (W != 0) {
-#pragma unroll
-      for (int j = 0; j < W; ++j) {
-        // the three values of a column are requested together, before their products (whose inline asm would otherwise pin
-        // every load right in front of its use)
-        const uint64_t col = (b * W + j) * N + x;
-        const fp v0 = fp_load(a.d_work + col), v1 = fp_load(a.p_evals + col), v2 = fp_load(a.b_work + col);
-        asm volatile("" ::: "memory");  // one scalar pair in registers at a time
-        acc = fp_add(acc, fp_mul2(v0, sc_pair(3u * j)));
-        asm volatile("" ::: "memory");
-        acc = fp_add(acc, fp_mul2(v1, sc_pair(3u * j + 1)));
-        asm volatile("" ::: "memory");
-        acc = fp_add(acc, fp_mul2(v2, sc_pair(3u * j + 2)));
-      }
-    } else {
-      for (uint32_t j = 0; j < width; ++j) {
-        const uint64_t col = (b * width + j) * N + x;
-        acc = fp_add(acc, fp_mul2(fp_load(a.d_work + col), sc_pair(3 * j)));
-        acc = fp_add(acc, fp_mul2(fp_load(a.p_evals + col), sc_pair(3 * j + 1)));
-        acc = fp_add(acc, fp_mul2(fp_load(a.b_work + col), sc_pair(3 * j + 2)));
-      }
-    }
+    const fp acc = lincomb_point<W>(a, b, x, width, sc_pair);
     fp_store(l_evals + b * N + x, acc);
     fp_to_wire_words(fp_canon(acc), w[r]);  // x.to_bytes(): 32 bytes big-endian (modp.py:94-95)
   }
@@ -367,6 +414,51 @@ __global__ void __launch_bounds__(TPB) stark_lincomb_leaves_kernel(StarkArgs a, 
   if (i == 0) {
     uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     store8(tree, z);  // nodes[0]: the reference keeps b'' there
+  }
+}
+// A narrow launch (one small proof): FOUR adjacent lanes share a permute4 row, one point each -- 3 W products and up to three
+// compressions in sequence instead of 12 W and three; lanes 0 and 2 hash the two leaf pairs from their neighbours' values, lane 0 the
+// parent (lane swaps inside the wave).  Same stores, same bytes.
+template <int W>
+__global__ void __launch_bounds__(TPB) stark_lincomb_leaves_narrow_kernel(StarkArgs a, const fp* scal, fp* l_evals, uint32_t* nodes) {
+  static_assert(TPB >= SHK_STARK_MAX_WIDTH * 12, "the scalar staging needs one thread per uint4");
+  __shared__ uint4 sc_lds[SHK_STARK_MAX_WIDTH * 12];
+  const uint64_t N = a.n, q = N >> 2;
+  const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
+  const uint64_t i = g >> 2, b = blockIdx.y;
+  const uint32_t r = (uint32_t)g & 3u;
+  const uint32_t width = W ? (uint32_t)W : a.width;
+  if (threadIdx.x < width * 12) sc_lds[threadIdx.x] = reinterpret_cast<const uint4*>(scal + b * width * 6)[threadIdx.x];
+  __syncthreads();
+  if (i >= q) return;  // the four lanes of a row leave together (TPB is a multiple of 4)
+  auto sc_pair = [&](uint32_t idx) {
+    const uint4 q0 = sc_lds[4 * idx], q1 = sc_lds[4 * idx + 1], q2 = sc_lds[4 * idx + 2], q3 = sc_lds[4 * idx + 3];
+    fp2 p;
+    p.w.v[0] = q0.x; p.w.v[1] = q0.y; p.w.v[2] = q0.z; p.w.v[3] = q0.w;
+    p.w.v[4] = q1.x; p.w.v[5] = q1.y; p.w.v[6] = q1.z; p.w.v[7] = q1.w;
+    p.w128.v[0] = q2.x; p.w128.v[1] = q2.y; p.w128.v[2] = q2.z; p.w128.v[3] = q2.w;
+    p.w128.v[4] = q3.x; p.w128.v[5] = q3.y; p.w128.v[6] = q3.z; p.w128.v[7] = q3.w;
+    return p;
+  };
+  uint32_t* tree = nodes + b * 2 * N * 8;
+  const uint64_t x = i + (uint64_t)r * q;
+  const fp acc = lincomb_point<W>(a, b, x, width, sc_pair);
+  fp_store(l_evals + b * N + x, acc);
+  uint32_t own[8], other[8];
+  fp_to_wire_words(fp_canon(acc), own);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) other[k] = (uint32_t)__shfl_xor((int)own[k], 1);
+  b2digest d = b2_hash_pair<false>(own, other);  // meaningful on the even lanes: hash(value r, value r + 1)
+  if ((r & 1u) == 0) store8(tree + (N / 2 + 2 * i + (r >> 1)) * 8, d.h);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) other[k] = (uint32_t)__shfl_xor((int)d.h[k], 2);
+  if (r == 0) {
+    const b2digest top = b2_hash_pair<false>(d.h, other);
+    store8(tree + (N / 4 + i) * 8, top.h);
+    if (i == 0) {
+      uint32_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      store8(tree, z);
+    }
   }
 }
 
@@ -437,12 +529,17 @@ hipError_t shk_stark_quotients_and_merkelize(const StarkArgs& a, uint32_t* d_nod
   if (a.n < 4) return hipErrorInvalidValue;
   const dim3 tgrid(grid_for(a.steps * a.batch)), grid(grid_for(a.n >> 2), a.batch), block(TPB);
   const bool wide = (a.n >> 2) * a.batch >= STARK_WIDE_THREADS;
+  // up to two waves per SIMD of rows: two lanes per row (stark_quotients_leaves_narrow_kernel)
+  const bool split = (a.n >> 2) * a.batch <= STARK_SPLIT_ROWS;
+  const dim3 sgrid(grid_for(a.n >> 1), a.batch);
   switch (a.width) {
 #define SHK_CASE(W)                                                                                   \
   case W:                                                                                             \
     hipLaunchKernelGGL(stark_trace_points_kernel<W>, tgrid, block, 0, st, a);                         \
     if (wide)                                                                                         \
       hipLaunchKernelGGL((stark_quotients_leaves_kernel<W, true>), grid, block, 0, st, a, d_nodes);  \
+    else if (split)                                                                                   \
+      hipLaunchKernelGGL(stark_quotients_leaves_narrow_kernel<W>, sgrid, block, 0, st, a, d_nodes);   \
     else                                                                                              \
       hipLaunchKernelGGL((stark_quotients_leaves_kernel<W, false>), grid, block, 0, st, a, d_nodes); \
     break;
@@ -474,12 +571,15 @@ hipError_t shk_stark_scalars(const uint32_t* d_mnodes, uint64_t tree_words, uint
 
 hipError_t shk_stark_lincomb_tree(const StarkArgs& a, const fp* d_scal, fp* d_l, uint32_t* d_lnodes, hipStream_t st) {
   if (a.n < 4) return hipErrorInvalidValue;
-  const dim3 grid(grid_for(a.n >> 2), a.batch);
+  const dim3 grid(grid_for(a.n >> 2), a.batch), ngrid(grid_for(a.n), a.batch);
   const bool wide = (a.n >> 2) * a.batch >= STARK_WIDE_THREADS;
+  const bool split = (a.n >> 2) * a.batch <= STARK_SPLIT4_ROWS;  // four lanes per row (stark_lincomb_leaves_narrow_kernel)
 #define SHK_LINCOMB(W)                                                                                              \
   do {                                                                                                              \
     if (wide)                                                                                                       \
       hipLaunchKernelGGL((stark_lincomb_leaves_kernel<W, true>), grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes); \
+    else if (split)                                                                                                 \
+      hipLaunchKernelGGL(stark_lincomb_leaves_narrow_kernel<W>, ngrid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes);  \
     else                                                                                                            \
       hipLaunchKernelGGL((stark_lincomb_leaves_kernel<W, false>), grid, dim3(TPB), 0, st, a, d_scal, d_l, d_lnodes); \
   } while (0)
