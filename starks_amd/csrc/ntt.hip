@@ -6,6 +6,10 @@
 #include "knobs.hpp"
 #include "ntt_kernels.cuh"
 
+#ifndef SHK_NARROW_HALF_TILES
+#define SHK_NARROW_HALF_TILES 128
+#endif
+
 namespace {
 
 template <int LOG_R, bool LAST, int TILE_LOG>
@@ -25,6 +29,17 @@ bool launch_narrow(const NttPassArgs& a, hipStream_t st, hipError_t* err) {
     const uint64_t tiles = (a.total + ((1ull << LOG_T) - 1)) >> LOG_T;
     if (kn.narrow_tiles <= 0 || tiles == 0 || tiles > (uint64_t)kn.narrow_tiles) return false;
     if (a.pass_index < 8 && kn.tile_logs[a.pass_index]) return false;  // a forced tile size means the tile-pass kernels
+    // Up to SHK_NARROW_HALF_TILES tiles: 512-element tiles, 256 threads -- the launch then has at most one wave per SIMD, and a level's
+    // product chain is not shared with a second wave of the same workgroup (radix <= 2^8: at least two columns / rows per tile)
+    if constexpr (LOG_R <= 8) {
+      if (tiles <= SHK_NARROW_HALF_TILES) {
+        constexpr int LOG_T9 = 9 - LOG_R;
+        const uint64_t tiles9 = (a.total + ((1ull << LOG_T9) - 1)) >> LOG_T9;
+        hipLaunchKernelGGL((ntt_narrow_pass_kernel<LOG_R, LOG_T9, LAST>), dim3((unsigned)tiles9), dim3(256), 0, st, a);
+        *err = hipGetLastError();
+        return true;
+      }
+    }
     hipLaunchKernelGGL((ntt_narrow_pass_kernel<LOG_R, LOG_T, LAST>), dim3((unsigned)tiles), dim3(1u << (LOG_R + LOG_T - 1)), 0, st, a);
     *err = hipGetLastError();
     return true;

@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 2), SHK_NTT_MIN_WAVES) n
 // Used below STARKHIP_NTT_NARROW_TILES tiles per launch (knobs.hpp; small transforms: the commits and proofs of 2^14..2^16-step traces).
 template <int LOG_R, int LOG_T, bool LAST>
 __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 1)) ntt_narrow_pass_kernel(NttPassArgs a) {
-  static_assert(LOG_R >= 2 && LOG_R <= 10 && LOG_T >= 0 && LOG_R + LOG_T == 10, "1024-element tiles");
+  static_assert(LOG_R >= 2 && LOG_R <= 10 && LOG_T >= 0 && (LOG_R + LOG_T == 10 || LOG_R + LOG_T == 9), "1024- or 512-element tiles");
   __shared__ __attribute__((aligned(16))) uint4 lds[2 << (LOG_R + LOG_T)];
   constexpr int R = 1 << LOG_R;
   const uint32_t tid = threadIdx.x;
