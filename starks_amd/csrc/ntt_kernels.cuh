@@ -463,6 +463,15 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 1)) ntt_narrow_pass_kern
   };
   fp x0, x1;
   uint32_t i_lo = 0;
+  // the twiddle pair of a level, w_R^((i mod half) * R / (2 half)), depends on the thread alone: it is requested one level ahead (the
+  // product's inline asm pins a load where the source has it, and a load right in front of its product is ~0.5 us of every level)
+  auto tw_of = [&](int q) {
+    const uint32_t half = 1u << q, pq = q == LOG_R - 1 ? p_in : p;
+    const uint32_t il = ((pq >> q) << (q + 1)) | (pq & (half - 1u));
+    return fp2_load(a.wR + ((il & (half - 1u)) << (LOG_R - 1 - q)));
+  };
+  fp2 tw_cur, tw_nxt;
+  if constexpr (LOG_R >= 2) tw_cur = tw_of(LOG_R - 1);
 #pragma unroll
   for (int q = LOG_R - 1; q >= 0; --q) {
     const uint32_t half = 1u << q;
@@ -478,10 +487,12 @@ __global__ void __launch_bounds__(1 << (LOG_R + LOG_T - 1)) ntt_narrow_pass_kern
       u = lds_get_at(lds, s_lo);
       v = lds_get_at(lds, s_hi);
     }
+    if (q > 1) tw_nxt = tw_of(q - 1);
     x0 = fp_add(u, v);
     x1 = fp_sub(u, v);
     if (q > 0) {
-      x1 = fp_mul2(x1, fp2_load(a.wR + ((i_lo & (half - 1u)) << (LOG_R - 1 - q))));  // w_R^((i mod half) * R / (2 half))
+      x1 = fp_mul2(x1, tw_cur);
+      if (q > 1) tw_cur = tw_nxt;
       lds_put_at(lds, s_lo, x0);
       lds_put_at(lds, s_hi, x1);
       __syncthreads();
