@@ -42,7 +42,7 @@ SEED = 0x5eed
 
 
 LOGNS = (17, 19, 21, 22, 23, 24)
-FRI_LOGSTEPS = (14, 16, 20)
+FRI_LOGSTEPS = (14, 16, 18, 20, 22)  # 22: the largest commit the index sampling admits (domain 2^25, utils.py:69)
 FRI_SEED = 0xF51
 
 

@@ -497,9 +497,10 @@ def test_full_size_fri_prove_then_verify(sa, logsteps):
         assert L.sh_dev_free(ctx, d) == 0
 
 
-@pytest.mark.parametrize("logsteps", [14, 16, 20])
+@pytest.mark.parametrize("logsteps", [14, 16, 18, 20, 22])
 def test_fri_commits_of_the_metric_vs_oracle_fixture(sa, logsteps):
-    """The commits bench.py times -- 2^14 (config 3's size), 2^16 (config 5's) and 2^20 steps ("FRI-commit ms for 2^20 trace") on the
+    """The commits bench.py times -- 2^14 (config 3's size), 2^16 (config 5's) and 2^20 steps ("FRI-commit ms for 2^20 trace") -- and
+    the largest one the reference's index sampling admits (2^22 steps, domain 2^25: utils.py:69; 5 min of oracle time), on the
     seeded degree < steps polynomial -- byte for byte against the flat proofs oracle/oracle.c:fri_rec wrote (the reference's loop,
     fri.py:189-266, with its per-round iNTT -> NTT and Lagrange fold; tests/golden/fri_large.json, generate_large.py --fri), from the
     coefficients a prover holds and from the zero-padded vector."""
