@@ -41,7 +41,7 @@ P = 2**256 - 2**32 * 351 + 1
 SEED = 0x5eed
 
 
-LOGNS = (17, 19, 21, 22, 23, 24)
+LOGNS = (17, 19, 21, 22, 23, 24, 25, 26)  # 25, 26: four-pass plans (1 and 2 GiB vectors)
 FRI_LOGSTEPS = (14, 16, 18, 20, 22)  # 22: the largest commit the index sampling admits (domain 2^25, utils.py:69)
 FRI_SEED = 0xF51
 
@@ -126,7 +126,13 @@ def merkle_main():
     nodes and the SHA-256 of the whole 2n x 32-byte node array (slot 0 = zeros, as sh_merkelize writes it)."""
     out = os.path.join(HERE, "merkle_large.json")
     cases = []
-    for logn in (20, 24):
+    if "--missing" in sys.argv[1:] and os.path.exists(out):
+        with open(out) as fh:
+            cases = json.load(fh)["cases"]
+    have = {c["logn"] for c in cases}
+    for logn in (20, 24, 26):  # 26: 2 GiB of leaves, 4 GiB of nodes (about 2 min)
+        if logn in have:
+            continue
         n = 1 << logn
         t0 = time.time()
         leaves = b"".join((int.from_bytes(hashlib.blake2s(struct.pack("<QQ", 7, i)).digest(), "big") % P).to_bytes(32, "big")
@@ -138,6 +144,7 @@ def merkle_main():
         print(case, flush=True)
         cases.append(case)
         del leaves, nodes
+    cases.sort(key=lambda c: c["logn"])
     with open(out, "w") as fh:
         json.dump({"generator": "tests/golden/generate_large.py --merkle (oracle/oracle.c:or_merkelize, pinned to the reference by merkle.json)",
                    "cases": cases}, fh, indent=1)

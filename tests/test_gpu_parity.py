@@ -1049,9 +1049,9 @@ def test_full_size_merkle_2_24_branches_verify(sa):
         L.sh_dev_free(ctx, dt)
 
 
-@pytest.mark.parametrize("logn", [20, 24])
+@pytest.mark.parametrize("logn", [20, 24, 26])
 def test_merkle_commit_at_size_vs_oracle_fixture(sa, logn):
-    """The Merkle commitment bench.py times (2^24 seeded leaves; 2^20 in its --quick mode): EVERY node of the tree against the tree
+    """The Merkle commitment bench.py times (2^24 seeded leaves; 2^20 in its --quick mode) and a 2^26-leaf one (4 GiB of nodes): EVERY node of the tree against the tree
     oracle/oracle.c hashed (tests/golden/merkle_large.json: root, three interior nodes, SHA-256 of all 2n nodes)."""
     import ctypes
     c = [c for c in load_golden("merkle_large.json")["cases"] if c["logn"] == logn][0]
@@ -1084,9 +1084,9 @@ def test_merkle_commit_at_size_vs_oracle_fixture(sa, logn):
 
 
 # ---- round 2: reference-independent pins for config 4, config 5 at its size, the new ABI entries -------------------------
-@pytest.mark.parametrize("logn", [17, 19, 21, 22, 23, 24])
+@pytest.mark.parametrize("logn", [17, 19, 21, 22, 23, 24, 25, 26])
 def test_ntt_large_digests_vs_oracle_fixture(sa, logn):
-    """Config 4 (2^24), 2^22 and the plan shapes no reference digest reaches densely -- 2^17 (config 3's domain, plan (9, 8)), 2^19 (config 5's domain, plan (9, 10)),
+    """Config 4 (2^24), 2^25 and 2^26 (four-pass plans, 1 and 2 GiB vectors), 2^22 and the plan shapes no reference digest reaches densely -- 2^17 (config 3's domain, plan (9, 8)), 2^19 (config 5's domain, plan (9, 10)),
     2^21 (the first three-pass plan) and 2^23 (the domain of the metric's 2^20-step FRI commit, 256 MiB row table): forward and
     inverse transforms of the seeded vector against the digests the C oracle produced (tests/golden/ntt_large.json; the
     oracle is pinned to the live reference up to 2^20)."""
@@ -1103,8 +1103,8 @@ def test_ntt_large_digests_vs_oracle_fixture(sa, logn):
     for inverse, key, head in ((0, "sha_fwd", "fwd_head"), (1, "sha_inv", "inv_head")):
         assert L.sh_dev_ntt(ctx, dx, dy, n, 1, w, inverse) == 0
         assert L.sh_dev_to_wire(ctx, dy, host, n) == 0
-        assert host.raw[:64].hex() == c[head]
-        assert hashlib.sha256(host.raw).hexdigest() == c[key], (logn, key)
+        assert bytes(host[:64]).hex() == c[head]
+        assert hashlib.sha256(host).hexdigest() == c[key], (logn, key)  # (the buffer itself: no second copy of up to 2 GiB)
     assert L.sh_dev_free(ctx, dx) == 0 and L.sh_dev_free(ctx, dy) == 0
 
 
