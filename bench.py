@@ -562,10 +562,14 @@ def alu_mix_peak(achieved):
         res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         src = "tools/alu_mix_bench, run by this bench.py on this GPU"
     except Exception:
-        try:
-            res = json.load(open(os.path.join(ROOT, "profiles", "r04_alu_mix_peak.json")))
-            src = "profiles/r04_alu_mix_peak.json (tools/alu_mix_bench not runnable here)"
-        except Exception:
+        for name in ("r05_alu_mix_peak.json", "r04_alu_mix_peak.json"):
+            try:
+                res = json.load(open(os.path.join(ROOT, "profiles", name)))
+                src = "profiles/%s (tools/alu_mix_bench not runnable here)" % name
+                break
+            except Exception:
+                continue
+        if res is None:
             return {}
     if "waves4" not in res:
         return {"peak_error": res.get("error")}
