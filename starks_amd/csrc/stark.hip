@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(TPB, (W <= 3 ? 4 : 1)) stark_quotients_leaves_
 // (four waves per SIMD as the one-lane form: a 2^16-step proof's 4096 waves are resident at once; the throughput form of the hash
 // rounds measured level there, profiles/r05_stark_narrow_lanes_ab.txt)
 template <int W>
-__global__ void __launch_bounds__(TPB, (W <= 3 ? 4 : 1)) stark_quotients_leaves_narrow_kernel(StarkArgs a, uint32_t* nodes) {
+__global__ void __launch_bounds__(TPB, (W <= 2 ? 4 : 1)) stark_quotients_leaves_narrow_kernel(StarkArgs a, uint32_t* nodes) {
   const uint64_t N = a.n, q = N >> 2;
   const uint64_t g = (uint64_t)blockIdx.x * TPB + threadIdx.x;
   const uint64_t i = g >> 1, b = blockIdx.y;
