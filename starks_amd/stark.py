@@ -210,3 +210,9 @@ class STARK(object):
             slope = (output_dim - input_value) * inv % p
             interpolant = (input_value - slope + slope * x) % p
             assert (p_of_x[dim] - b_of_x[dim] * z2 - interpolant) % p == 0
+
+
+# the module-level building blocks of mk_proof under the reference's names (stark.py:27-177): see stark_polys.py
+from .stark_polys import (construct_trace_polynomials, construct_constraint_polynomials, construct_remainder_polynomials,  # noqa: E402,F401
+                          construct_boundary_polynomials, compute_pseudorandom_linear_combination_1d,
+                          compute_pseudorandom_linear_combination)

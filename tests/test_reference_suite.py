@@ -245,3 +245,77 @@ def test_stark__test_varying_quintic_stark(F):
     from starks_amd.multivariate_polynomial import generate_Xi_s
     X = generate_Xi_s(F, 6)
     _prove_and_verify(F, 6, 8, [1, 2, 3, 4, 5, 6], X[:5] + [X[0] * X[1] * X[2] * X[3] * X[4] * X[5]])
+
+
+# ---- the module-level pieces of mk_proof (stark.py:27-177), as the reference's commented tests assemble them -----------------------
+def _system(F, c):
+    from starks_amd.multivariate_polynomial import multivariates_over
+    mv = multivariates_over(F, c["width"]).factory
+    return [mv({tuple(k): F(v) for k, v in d}) for d in c["step_polys"]]
+
+
+def test_stark__test_trace_polynomials(F):
+    """test_stark.py:63-87 -- [X2, X1 + 2 X2^2] from (2, 5), 128 steps: every trace polynomial takes the witness's values on the
+    powers of G1"""
+    from starks_amd.air import AIR
+    from starks_amd.multivariate_polynomial import generate_Xi_s
+    from starks_amd.stark import STARK, construct_trace_polynomials
+    from starks_amd.utils import get_power_cycle
+    X1, X2 = generate_Xi_s(F, 2)
+    step_polys = [X2, X1 + 2 * X2**2]
+    comp = AIR(F, 2, [F(2), F(5)], 128, step_polys, 8)
+    witness = comp.generate_witness()
+    params = STARK(F, 128, 8, 2, step_polys)
+    trace_polys = construct_trace_polynomials(witness, params.field, params.G1)
+    assert len(trace_polys) == 2
+    xs = get_power_cycle(params.G1, params.field)
+    for dim in range(2):
+        for ind, x in enumerate(xs):
+            assert witness[dim][ind] == trace_polys[dim](x)
+
+
+def test_stark__test_constraint_polynomials_and_the_pieces_of_mk_proof(F):
+    """test_stark.py:89-109, :111-163, :165-213 -- the constraint, remainder and boundary polynomials, the packed tree over their
+    evaluations, the pseudorandom linear combination and its tree, assembled from the module-level functions as those tests do;
+    checked against what the LIVE reference's functions of the same names returned (tests/golden/stark.json: coefficients of
+    every trace / remainder / boundary polynomial, m_root, l_root) and against mk_proof's own roots."""
+    from conftest import load_golden
+    from starks_amd import stark
+    from starks_amd.fft import NonBinaryFFT
+    from starks_amd.merkle_tree import merkelize, merkelize_polynomial_evaluations
+    from starks_amd.utils import get_pseudorandom_indices
+    for c in load_golden("stark.json"):
+        if c["steps"] > 256:
+            continue
+        width, steps, ext = c["width"], c["steps"], c["ext"]
+        step_polys = _system(F, c)
+        witness = [[F(int(v, 16)) for v in col] for col in c["witness"]]
+        boundary = [(0, j, F(v)) for j, v in enumerate(c["inputs"])]
+        S = stark.STARK(F, steps, ext, width, step_polys)
+        tps = stark.construct_trace_polynomials(witness, F, S.G1)
+        cps = stark.construct_constraint_polynomials(step_polys, tps, F, S.G1, width)
+        assert len(cps) == width
+        dps = stark.construct_remainder_polynomials(cps, F, steps, S.last_step_position)
+        bps = stark.construct_boundary_polynomials(tps, witness, boundary, F, S.last_step_position, width)
+        as_hex = lambda polys: [["%064x" % int(a) for a in pl.coefficients] for pl in polys]  # noqa: E731
+        assert as_hex(tps) == c["trace_polys"], c["name"]
+        assert as_hex(dps) == c["remainder_polys"], c["name"]
+        assert as_hex(bps) == c["boundary_polys"], c["name"]
+        solver = NonBinaryFFT(F, S.G2)
+        mtree = merkelize_polynomial_evaluations(width, [solver.fft(pl) for pl in tps + dps + bps])
+        assert mtree[1].hex() == c["m_root"], c["name"]
+        l_poly = stark.compute_pseudorandom_linear_combination(mtree[1], tps, dps, bps, F, S.G2, S.precision, steps, width)
+        l_mtree = merkelize(solver.fft(l_poly))
+        assert l_mtree[1].hex() == c["l_root"], c["name"]
+        indices = get_pseudorandom_indices(l_mtree[1], S.precision, count=80, exclude_multiples_of=ext)
+        assert len(indices) == 80 and all(i % ext for i in indices)
+        proof = S.mk_proof(witness, boundary)  # the device prover commits to the same two roots
+        assert proof[0] == mtree[1] and proof[1] == l_mtree[1]
+        # a witness that is not a trace: the division by Z leaves a remainder (stark.py:76)
+        if steps == 32:
+            bad = [list(col) for col in witness]
+            bad[-1][steps // 2] = bad[-1][steps // 2] + 1
+            with pytest.raises(AssertionError):
+                btps = stark.construct_trace_polynomials(bad, F, S.G1)
+                stark.construct_remainder_polynomials(stark.construct_constraint_polynomials(step_polys, btps, F, S.G1, width), F, steps,
+                                                      S.last_step_position)
