@@ -57,3 +57,19 @@ def mimc_trace(t0, steps):
     for i in range(steps - 1):
         out.append((out[-1]**3 + ks[i % 64]) % MIMC_P)
     return out
+
+
+def generate_Xi_s(field, width):
+    """utils.py:40-56: the index polynomials X_1 .. X_width"""
+    from .multivariate_polynomial import generate_Xi_s as gen
+    return gen(field, width)
+
+
+def is_a_power_of_2(x):
+    """utils.py:93-94"""
+    return x >= 1 and x & (x - 1) == 0
+
+
+def plus_one(num):
+    """utils.py:11-12 (the reference's typed-function example, test_utils.py:32-34)"""
+    return num + 1

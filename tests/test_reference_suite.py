@@ -119,6 +119,15 @@ def test_utils__test_get_power_cycle(F):
     assert len(cyc) == 4096 and int(cyc[1]) == int(g) and int(cyc[4095]) * int(g) % P == 1
 
 
+def test_utils__test_plus_one_and_the_small_helpers(F):
+    """test_utils.py:32-34, and the helpers the reference's STARK tests import from utils (generate_Xi_s, is_a_power_of_2)"""
+    from starks_amd.utils import generate_Xi_s, is_a_power_of_2, plus_one
+    assert plus_one(4) == 5
+    assert [is_a_power_of_2(x) for x in (1, 2, 3, 4, 6, 1 << 20, (1 << 20) + 2)] == [True, True, False, True, False, True, False]
+    X1, X2 = generate_Xi_s(F, 2)
+    assert int((X1 + X2**3)([F(2), F(5)])) == 127
+
+
 def test_utils__test_mimc():
     """test_utils.py:11-18 -- mimc(5, 3, [2, 7]) runs (the reference asserts nothing); here also its value"""
     from starks_amd.utils import mimc
